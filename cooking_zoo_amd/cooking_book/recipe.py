@@ -1,0 +1,98 @@
+"""Recipe graphs, host side.
+
+Same public shape as the reference's `RecipeNode` / `Recipe` (cooking_book/recipe.py:12-40,74-75) so
+that user code building custom recipes keeps working, plus `flatten()` which turns a graph into the
+fixed-width node table the kernels evaluate (recipe.py:77-104 is evaluated on the device, not here).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from cooking_zoo_amd import soa
+from cooking_zoo_amd.cooking_world.constants import ChopFoodStates, BlenderFoodStates
+
+
+class RecipeNode:
+    def __init__(self, root_type, id_num, name, parent=None, conditions=None, contains=None, objects_to_seek=None):
+        self.parent = parent
+        self.marked = False
+        self.id_num = id_num
+        self.root_type = root_type
+        self.conditions = conditions or []
+        self.contains = contains or []
+        self.world_objects = []
+        self.name = name
+        self.child_nodes = objects_to_seek or []
+
+    def is_leaf(self):
+        return not bool(self.contains)
+
+
+def _condition_code(conditions):
+    """(attr, value) pairs -> one device condition code.  The device evaluates at most one
+    state predicate per node (every recipe the reference ships has zero or one)."""
+    if not conditions:
+        return soa.COND_NONE
+    if len(conditions) > 1:
+        raise ValueError("at most one (attribute, value) condition per recipe node is supported")
+    attr, value = conditions[0]
+    value = getattr(value, "value", value)
+    table = {("chop_state", ChopFoodStates.CHOPPED.value): soa.COND_CHOPPED,
+             ("chop_state", ChopFoodStates.FRESH.value): soa.COND_NOT_CHOPPED,
+             ("blend_state", BlenderFoodStates.MASHED.value): soa.COND_MASHED,
+             ("blend_state", BlenderFoodStates.FRESH.value): soa.COND_NOT_MASHED}
+    try:
+        return table[(attr, value)]
+    except KeyError:
+        raise ValueError(f"unsupported recipe condition {conditions[0]!r}") from None
+
+
+class Recipe:
+    def __init__(self, root_node: RecipeNode, num_goals: int, name: str = ""):
+        self.root_node = root_node
+        self.name = name
+        self.node_list = [root_node] + self.expand_child_nodes(root_node)
+        if len(self.node_list) > soa.MAX_NODES:
+            raise ValueError(f"recipe graphs are limited to {soa.MAX_NODES} nodes")
+        self.num_goals = num_goals
+        self.marks = 0           # bit j = node_list[j].marked, refreshed from the device after each step
+        self.goal_encoding = self.goals_completed(num_goals)
+
+    def expand_child_nodes(self, node: RecipeNode):
+        child_nodes = []
+        for child in node.contains:
+            child_nodes.extend(self.expand_child_nodes(child))
+        return node.contains + child_nodes
+
+    def set_marks(self, marks: int):
+        self.marks = int(marks)
+        for j, node in enumerate(self.node_list):
+            node.marked = bool((self.marks >> j) & 1)
+
+    def goals_completed(self, num_goals):
+        goals = np.zeros(num_goals, dtype=np.int32)
+        for j, node in enumerate(self.node_list):
+            goals[node.id_num] = int(not (self.marks >> j) & 1)
+        return goals
+
+    def completed(self):
+        return bool(self.marks & 1)
+
+    def flatten(self) -> np.ndarray:
+        """-> uint32[1 + MAX_NODES]: n_nodes, then per node  cls | cond<<8 | child_mask<<16 | counts<<24.
+        `counts` marks the last node carrying a given goal id (goals[id] is overwritten by later nodes,
+        recipe.py:38-39, so only that one contributes to sum(goals))."""
+        out = np.zeros(1 + soa.MAX_NODES, dtype=np.uint32)
+        out[0] = len(self.node_list)
+        index = {id(n): j for j, n in enumerate(self.node_list)}
+        last_with_id = {}
+        for j, n in enumerate(self.node_list):
+            last_with_id[n.id_num] = j
+        for j, n in enumerate(self.node_list):
+            child_mask = 0
+            for c in n.contains:
+                child_mask |= 1 << index[id(c)]
+            counts = 1 if last_with_id[n.id_num] == j else 0
+            out[1 + j] = (soa.class_node_id(n.name) | (_condition_code(n.conditions) << 8) | (child_mask << 16)
+                          | (counts << 24))
+        return out

@@ -1,0 +1,58 @@
+"""Loader for the golden fixtures written by tools/gen_golden.py (data only)."""
+from __future__ import annotations
+
+import glob
+import json
+import os
+
+import numpy as np
+
+from cooking_zoo_amd import soa
+from cooking_zoo_amd.cooking_book.recipe_drawer import RECIPES
+from cooking_zoo_amd.cooking_world.engine.load_level import load_meta_file
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RECIPE_NAMES = list(RECIPES.keys())
+
+
+def recipe_table():
+    return np.stack([RECIPES[n]().flatten() for n in RECIPE_NAMES])
+
+
+def golden_sets():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                  if not os.path.basename(p).startswith("layouts_"))
+
+
+class Episode:
+    def __init__(self, z, i, meta_ep):
+        g = lambda k: z[f"e{i}_{k}"]
+        self.dims = soa.Dims(*[int(v) for v in g("dims")])
+        self.states, self.obs, self.actions = g("states"), g("obs"), g("actions")
+        self.rewards, self.terms, self.truncs = g("rewards"), g("terms"), g("truncs")
+        self.statics = meta_ep["statics"]
+        self.class_order = meta_ep["class_order"]
+        self.seed = meta_ep["seed"]
+        self.policy = meta_ep["policy"]
+
+    def static_table(self):
+        W = self.dims.W
+        off, cells = [0], []
+        for name in soa.STATIC_CLASSES:
+            cells += [y * W + x for x, y in self.statics.get(name, [])]
+            off.append(len(cells))
+        return np.asarray(off, dtype=np.int32), np.asarray(cells, dtype=np.int16)
+
+    def static_lists(self):
+        W = self.dims.W
+        return {k: [y * W + x for x, y in v] for k, v in self.statics.items()}
+
+
+class GoldenSet:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.cfg = json.loads(bytes(z["meta"]).decode())
+        self.meta = load_meta_file(self.cfg["meta_file"])
+        self.episodes = [Episode(z, i, m) for i, m in enumerate(self.cfg["episodes"])]
+        self.scheme = 3 if self.cfg["action_scheme"] == "scheme3" else 1

@@ -1,0 +1,76 @@
+"""Pins the oracle: every golden trace captured from the unmodified reference must replay bit-exactly
+through oracle/cz_oracle.c (state, float64 observations, float64 rewards, flags)."""
+import numpy as np
+import pytest
+
+from cooking_zoo_amd import soa
+from golden_io import GoldenSet, golden_sets, recipe_table
+from oracle_binding import Oracle
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def make_oracle(gs, ep, **kw):
+    off, cells = ep.static_table()
+    return Oracle(ep.dims, gs.meta, recipe_table(), [(ep.states[0], off, cells)], scheme=gs.scheme,
+                  max_steps=gs.cfg["max_steps"], end_condition_all=gs.cfg["end_condition_all_dishes"],
+                  num_recipes=len(gs.cfg["recipes"]), reward_scheme=gs.cfg.get("reward_scheme"), **kw)
+
+
+def same_state(dims, a, b):
+    a, b = a.copy(), b.copy()
+    a[soa.W_STATUS] = b[soa.W_STATUS] = 0          # the reference has no status word
+    return np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", golden_sets())
+def test_oracle_replays_golden(name):
+    gs = GoldenSet(name)
+    assert gs.episodes
+    for ei, ep in enumerate(gs.episodes):
+        orc = make_oracle(gs, ep)
+        rec = ep.states[0].copy()
+        # reset path: marks re-evaluated from the initial world, obs of the fresh world
+        rec2 = ep.states[0].copy()
+        rec2[soa.W_MARKS] = 0xDEAD
+        obs0 = np.empty((ep.dims.A, ep.dims.F))
+        assert orc.reset_env(rec2, 0, obs0) == 0
+        assert same_state(ep.dims, rec2, ep.states[0]), f"{name} ep{ei} reset"
+        assert np.array_equal(bits(obs0), bits(ep.obs[0])), f"{name} ep{ei} reset obs"
+        assert np.array_equal(bits(orc.observe(rec)), bits(ep.obs[0]))
+        for t in range(len(ep.actions)):
+            err, obs, rew, term, trunc = orc.step_env(rec, ep.actions[t])
+            ctx = f"{name} ep{ei} (seed {ep.seed}, {ep.policy}) step {t} actions {ep.actions[t].tolist()}"
+            assert err == 0, f"{ctx}: oracle error {err}"
+            if not same_state(ep.dims, rec, ep.states[t + 1]):
+                pytest.fail(f"{ctx}: state differs\n-- oracle\n{soa.describe_record(ep.dims, rec)}\n-- reference\n"
+                            f"{soa.describe_record(ep.dims, ep.states[t + 1])}\n-- before\n"
+                            f"{soa.describe_record(ep.dims, ep.states[t])}")
+            assert np.array_equal(bits(rew), bits(ep.rewards[t])), f"{ctx}: reward {rew} vs {ep.rewards[t]}"
+            assert np.array_equal(term, ep.terms[t]) and np.array_equal(trunc, ep.truncs[t]), ctx
+            if not np.array_equal(bits(obs), bits(ep.obs[t + 1])):
+                bad = np.argwhere(bits(obs) != bits(ep.obs[t + 1]))
+                pytest.fail(f"{ctx}: obs differs at {bad[:8].tolist()}")
+
+
+def test_kat_c3_known_answer():
+    """29 x -0.0125 then 19.9875 with terminated=True, sum 19.625."""
+    import hashlib
+    gs = GoldenSet("kat_c3")
+    ep = gs.episodes[0]
+    orc = make_oracle(gs, ep)
+    rec = ep.states[0].copy()
+    h = hashlib.sha256()
+    h.update(orc.observe(rec)[0].tobytes())
+    total = 0.0
+    for t in range(30):
+        err, obs, rew, term, trunc = orc.step_env(rec, ep.actions[t])
+        h.update(obs[0].tobytes())
+        total += rew[0]
+        assert rew[0] == (-0.0125 if t < 29 else 19.9875)
+        assert bool(term[0]) == (t == 29) and not trunc[0]
+    assert abs(total - 19.625) < 1e-12
+    assert h.hexdigest().startswith("24e17ccb854352dd")
+    assert soa.unpack_agent(rec[soa.AGENT_WORD0])[:2] == (2, 1)

@@ -1,0 +1,581 @@
+#!/usr/bin/env python3
+"""Generate golden parity fixtures by running the UNMODIFIED reference in this container.
+
+Runs only where /root/reference exists (the build container).  It imports the reference
+(`cooking_zoo.environment.cooking_env.CookingEnvironment`) through the import-time stand-ins in
+tools/refshim (gymnasium / pettingzoo / pygame are not installed; the stand-ins are plumbing only,
+SURVEY.md Appendix C), drives `reset()` / `accumulated_step()` / `observe()` and dumps, per step,
+
+  * the full world state converted to the flat record of cooking_zoo_amd/soa.py,
+  * the float64 feature-vector observation of every agent,
+  * rewards (float64), terminations, truncations,
+
+as compressed .npz files under tests/golden/.  The files are data only (inputs + expected outputs);
+nothing of the reference's source travels.  While converting, the generator ASSERTS the structural
+invariants the flat model relies on (derived static content, slot order == get_objects_at order,
+Bread clones appended last), so a violated assumption fails here, not silently on the GPU.
+
+Usage:  python tools/gen_golden.py [--only NAME] [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import random
+import sys
+from collections import defaultdict, deque
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = "/root/reference"
+
+
+def import_reference():
+    if not os.path.isdir(REFERENCE):
+        raise SystemExit("reference not present: golden fixtures can only be regenerated in the build container")
+    sys.path.insert(0, os.path.join(REPO, "tools", "refshim"))
+    sys.path.insert(1, REFERENCE)
+    sys.path.insert(2, REPO)
+
+
+import_reference()
+
+from cooking_zoo.environment.cooking_env import CookingEnvironment, parallel_env  # noqa: E402
+from cooking_zoo.cooking_world import world_objects as wo  # noqa: E402
+from cooking_zoo.cooking_world.abstract_classes import (  # noqa: E402
+    DynamicObject, StaticObject, ContentObject, ActionObject)
+from cooking_zoo.cooking_world.constants import (  # noqa: E402
+    ChopFoodStates, BlenderFoodStates, ActionObjectState)
+from cooking_zoo.cooking_agents.cooking_agent import CookingAgent  # noqa: E402
+
+from cooking_zoo_amd import soa  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------
+# reference world -> flat record
+# ------------------------------------------------------------------------------------------------
+
+class SlotMap:
+    """Assigns dynamic-object slots for one episode: class-major in `world_objects` key order,
+    list order inside a class, Bread clone head-room directly after the Bread originals."""
+
+    def __init__(self, world, max_dyn):
+        self.class_order = [k for k, v in world.world_objects.items()
+                            if issubclass(wo.StringToClass[k], DynamicObject) and len(v) > 0]
+        self.base = {}
+        self.cap = {}
+        s = 0
+        for k in self.class_order:
+            n = len(world.world_objects[k])
+            self.base[k] = s
+            self.cap[k] = 2 * n if k == "Bread" else n
+            s += self.cap[k]
+        self.used = s
+        assert s <= max_dyn, (s, max_dyn)
+
+    def slots(self, world):
+        """dict id(obj) -> slot, list of (slot, obj) in slot order."""
+        out = {}
+        ordered = []
+        keys = [k for k, v in world.world_objects.items()
+                if issubclass(wo.StringToClass[k], DynamicObject) and len(v) > 0]
+        assert keys == self.class_order, (keys, self.class_order)
+        for k in keys:
+            lst = world.world_objects[k]
+            assert len(lst) <= self.cap[k], (k, len(lst), self.cap[k])
+            for i, o in enumerate(lst):
+                out[id(o)] = self.base[k] + i
+                ordered.append((self.base[k] + i, o))
+        return out, ordered
+
+
+def static_at(world):
+    grid = {}
+    for k, lst in world.world_objects.items():
+        if issubclass(wo.StringToClass[k], StaticObject):
+            for o in lst:
+                assert o.location not in grid
+                grid[o.location] = o
+    assert len(grid) == world.width * world.height
+    return grid
+
+
+def world_to_record(env, dims, slotmap, layout_id=0, recipe_ids=None):
+    world = env.world
+    rec = soa.new_record(dims)
+    rec[soa.W_T] = env.t
+    marks = 0
+    for r, g in enumerate(env.recipe_graphs):
+        assert len(g.node_list) <= soa.MAX_NODES
+        for j, node in enumerate(g.node_list):
+            if node.marked:
+                marks |= 1 << (8 * r + j)
+    rec[soa.W_MARKS] = marks
+    rec[soa.W_LAYOUT] = layout_id
+    rid = [0xFF] * 4
+    for i, v in enumerate(recipe_ids or []):
+        rid[i] = v
+    rec[soa.W_RECIPES] = rid[0] | (rid[1] << 8) | (rid[2] << 16) | (rid[3] << 24)
+
+    slot_of, ordered = slotmap.slots(world)
+    held = {}
+    for a, ag in enumerate(world.agents):
+        hs = -1
+        if ag.holding is not None:
+            hs = slot_of[id(ag.holding)]
+            held[id(ag.holding)] = a
+            assert ag.holding.location == ag.location
+        rec[soa.AGENT_WORD0 + a] = soa.pack_agent(ag.location[0], ag.location[1], ag.orientation, hs)
+
+    grid = static_at(world)
+    cells = soa.record_cells(dims, rec)
+    for (x, y), s in grid.items():
+        t = soa.STATIC_CLASSES.index(type(s).__name__)
+        v = t
+        if isinstance(s, ActionObject) and s.status == ActionObjectState.READY:
+            v |= soa.CELL_READY
+        if isinstance(s, wo.Blender) and s.toggle:
+            v |= soa.CELL_TOGGLE
+        if isinstance(s, wo.Switch):
+            assert not s.button_pressed          # transient inside a step only
+            if s.switch_active:
+                v |= soa.CELL_ACTIVE
+        if isinstance(s, wo.Block) and s.walkable:
+            v |= soa.CELL_WALK
+        if not isinstance(s, wo.Block):
+            assert s.walkable == (t in (soa.FLOOR, soa.SWITCH))
+        cells[y * dims.W + x] = v
+
+    container = {}
+    for slot, o in ordered:
+        if isinstance(o, wo.Plate):
+            for seq, c in enumerate(o.content):
+                assert id(c) not in container
+                container[id(c)] = (slot, seq)
+                assert c.location == o.location
+    for slot, o in ordered:
+        cls = soa.DYNAMIC_CLASSES.index(type(o).__name__)
+        flags = soa.DYN_ALIVE
+        if getattr(o, "chop_state", None) == ChopFoodStates.CHOPPED:
+            flags |= soa.DYN_CHOPPED
+        if getattr(o, "blend_state", None) == BlenderFoodStates.MASHED:
+            flags |= soa.DYN_MASHED
+        if hasattr(o, "blend_state"):
+            assert o.blend_state != BlenderFoodStates.IN_PROGRESS
+        if o.free:
+            flags |= soa.DYN_FREE
+        rec[dims.dyn0_word0 + slot] = soa.pack_dyn0(o.location[0], o.location[1], cls, flags)
+        cs, seq = container.get(id(o), (-1, 0))
+        rec[dims.dyn1_word0 + slot] = soa.pack_dyn1(cs, seq)
+    # reserved (not yet alive) Bread clone slots carry the class so the allocator can find them
+    if "Bread" in slotmap.base:
+        n_alive = len(world.world_objects["Bread"])
+        for i in range(n_alive, slotmap.cap["Bread"]):
+            rec[dims.dyn0_word0 + slotmap.base["Bread"] + i] = soa.pack_dyn0(0, 0, soa.BREAD, 0)
+
+    # ---- invariants of the flat model, checked against the live reference objects
+    for (x, y), s in grid.items():
+        here = [(slot, o) for slot, o in ordered if o.location == (x, y)]
+        # get_objects_at(DynamicObject) order == slot order
+        ref_order = world.get_objects_at((x, y), DynamicObject)
+        assert [id(o) for _, o in here] == [id(o) for o in ref_order]
+        if isinstance(s, (wo.Floor, wo.Switch, wo.Block)):
+            assert all(isinstance(c, wo.Agent) for c in s.content)
+            continue
+        direct = [o for _, o in here if id(o) not in container and id(o) not in held]
+        assert [id(o) for o in direct] == [id(o) for o in s.content], (type(s).__name__, (x, y))
+    return rec
+
+
+def layout_arrays(env, dims, slotmap):
+    """Initial state of a freshly reset env (also the reset image of the layout pool)."""
+    rec = world_to_record(env, dims, slotmap)
+    return rec
+
+
+def static_lists(env):
+    """Per static class, cell positions in world_objects list order (needed for obs ordering)."""
+    world = env.world
+    out = {}
+    for k, lst in world.world_objects.items():
+        if issubclass(wo.StringToClass[k], StaticObject) and k != "Floor":
+            out[k] = [list(o.location) for o in lst]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# policies
+# ------------------------------------------------------------------------------------------------
+
+DIRS = {1: (-1, 0), 2: (1, 0), 3: (0, 1), 4: (0, -1)}
+
+
+class Bumper:
+    """Random 'walk up to a non-walkable cell and use it' policy: dense coverage of pick/place/
+    chop/blend/plate/deliver transitions, far denser than uniform random actions."""
+
+    def __init__(self, rng, scheme, eps=0.15):
+        self.rng, self.scheme, self.eps = rng, scheme, eps
+        self.goal = None
+
+    def pick_goal(self, world):
+        grid = static_at(world)
+        cand = []
+        for loc, s in grid.items():
+            if isinstance(s, (wo.Floor, wo.Switch)):
+                if isinstance(s, wo.Switch):
+                    cand += [loc] * 3
+                continue
+            w = 1
+            if world.get_objects_at(loc, DynamicObject):
+                w += 4
+            if isinstance(s, (wo.Cutboard, wo.Blender, wo.Deliversquare)):
+                w += 4
+            if isinstance(s, wo.Block):
+                w += 2
+            cand += [loc] * w
+        self.goal = cand[self.rng.integers(len(cand))]
+
+    def act(self, world, idx):
+        n_act = 5 if self.scheme == "scheme3" else 8
+        if self.rng.random() < self.eps:
+            return int(self.rng.integers(n_act))
+        if self.goal is None or self.rng.random() < 0.03:
+            self.pick_goal(world)
+        ag = world.agents[idx]
+        grid = static_at(world)
+        gx, gy = self.goal
+        if grid[self.goal].walkable:            # a Switch (or open Block): just walk onto it
+            targets = {self.goal}
+        else:
+            targets = {(gx - dx, gy - dy) for dx, dy in DIRS.values()}
+        # adjacent: bump / interact
+        for a, (dx, dy) in DIRS.items():
+            if (ag.location[0] + dx, ag.location[1] + dy) == self.goal and not grid[self.goal].walkable:
+                if self.rng.random() < 0.5:
+                    self.goal = None
+                if self.scheme == "scheme3":
+                    return a
+                if ag.orientation != a:
+                    return a
+                return int(self.rng.choice([5, 5, 5, 5, 7, 7, 6]))
+        if ag.location == self.goal:
+            self.goal = None
+            return int(self.rng.integers(n_act))
+        # BFS over walkable cells
+        prev = {ag.location: None}
+        dq = deque([ag.location])
+        found = None
+        while dq:
+            cur = dq.popleft()
+            if cur in targets:
+                found = cur
+                break
+            for a, (dx, dy) in DIRS.items():
+                nx = (cur[0] + dx, cur[1] + dy)
+                if nx in prev or nx not in grid or not grid[nx].walkable:
+                    continue
+                prev[nx] = (cur, a)
+                dq.append(nx)
+        if found is None or found == ag.location:
+            self.goal = None
+            return int(self.rng.integers(n_act))
+        cur = found
+        while prev[cur][0] != ag.location:
+            cur = prev[cur][0]
+        return prev[cur][1]
+
+
+class Heuristic:
+    """The reference's own heuristic agent (cooking_agents/cooking_agent.py) as a trace generator."""
+
+    def __init__(self, rng, recipe, name, eps=0.1):
+        self.rng, self.eps = rng, eps
+        self.agent = CookingAgent(recipe, name)
+
+    def act(self, world, idx):
+        if self.rng.random() < self.eps:
+            return int(self.rng.integers(5))
+        objects = defaultdict(list)
+        objects.update(world.world_objects)
+        objects["Agent"] = world.agents
+        try:
+            return int(self.agent.step(objects))
+        except Exception:
+            return int(self.rng.integers(5))
+
+
+class Uniform:
+    def __init__(self, rng, scheme):
+        self.rng, self.n = rng, (5 if scheme == "scheme3" else 8)
+
+    def act(self, world, idx):
+        return int(self.rng.integers(self.n))
+
+
+class Scripted:
+    def __init__(self, actions):
+        self.actions, self.i = list(actions), 0
+
+    def act(self, world, idx):
+        a = self.actions[self.i] if self.i < len(self.actions) else 0
+        self.i += 1
+        return int(a)
+
+
+# ------------------------------------------------------------------------------------------------
+# episode capture
+# ------------------------------------------------------------------------------------------------
+
+RECIPE_NAMES = ["TomatoSalad", "TomatoLettuceSalad", "CarrotBanana", "MashedCarrotBanana", "CucumberOnion",
+                "AppleWatermelon", "TomatoLettuceOnionSalad", "no_recipe"]
+
+
+def level_max_dyn(level_path_or_name):
+    if level_path_or_name.endswith(".json"):
+        p = level_path_or_name
+    else:
+        p = os.path.join(REFERENCE, "cooking_zoo", "utils", "level", level_path_or_name + ".json")
+    with open(p) as f:
+        lv = json.load(f)
+    n = 0
+    for d in lv["DYNAMIC_OBJECTS"]:
+        (name, spec), = d.items()
+        n += spec["COUNT"] * (2 if name == "Bread" else 1)
+    return n
+
+
+def capture_episode(cfg, seed, policy_name, max_len=None):
+    """Returns dict of arrays for one episode (reset + steps until done / max_len)."""
+    random.seed(seed)
+    np.random.seed(seed)
+    rng = np.random.default_rng(seed + 7919)
+    env = CookingEnvironment(level=cfg["level"], meta_file=cfg["meta_file"], num_agents=cfg["num_agents"],
+                             max_steps=cfg["max_steps"], recipes=cfg["recipes"],
+                             obs_spaces=["feature_vector"] * cfg["num_agents"],
+                             end_condition_all_dishes=cfg["end_condition_all_dishes"],
+                             action_scheme=cfg["action_scheme"], reward_scheme=cfg.get("reward_scheme"))
+    env.reset()
+    world = env.world
+    A = cfg["num_agents"]
+    F = env.feature_vector_representation_length
+    D = cfg["max_dyn"]
+    dims = soa.Dims(world.width, world.height, D, A, F)
+    slotmap = SlotMap(world, D)
+    recipe_ids = [RECIPE_NAMES.index(r) for r in cfg["recipes"]]
+
+    scheme = cfg["action_scheme"]
+    pols = []
+    for i in range(A):
+        if policy_name == "uniform":
+            pols.append(Uniform(rng, scheme))
+        elif policy_name == "bumper":
+            pols.append(Bumper(rng, scheme))
+        elif policy_name == "heuristic":
+            pols.append(Heuristic(rng, cfg["recipes"][i], f"agent-{i + 1}"))
+        elif policy_name == "mixed":
+            pols.append(Heuristic(rng, cfg["recipes"][i], f"agent-{i + 1}", eps=0.2) if i % 2 == 0
+                        else Bumper(rng, scheme))
+        elif isinstance(policy_name, (list, tuple)):
+            pols.append(Scripted([row[i] for row in policy_name]))
+        else:
+            raise ValueError(policy_name)
+
+    states = [world_to_record(env, dims, slotmap, 0, recipe_ids)]
+    obs = [np.stack([env.observe(a) for a in env.possible_agents])]
+    assert obs[0].dtype == np.float64 and obs[0].shape == (A, F)
+    actions, rewards, terms, truncs = [], [], [], []
+    statics = static_lists(env)
+    limit = max_len or cfg["max_steps"]
+    for step in range(limit):
+        act = [p.act(world, i) for i, p in enumerate(pols)]
+        env.accumulated_step(act)
+        actions.append(act)
+        rewards.append([float(env.rewards[a]) for a in env.possible_agents])
+        for a in env.possible_agents:
+            assert isinstance(env.rewards[a], (float, np.floating)), type(env.rewards[a])
+        terms.append([bool(env.terminations[a]) for a in env.possible_agents])
+        truncs.append([bool(env.truncations[a]) for a in env.possible_agents])
+        states.append(world_to_record(env, dims, slotmap, 0, recipe_ids))
+        o = np.stack([env.observe(a) for a in env.possible_agents])
+        assert o.dtype == np.float64
+        obs.append(o)
+        if any(terms[-1]) or any(truncs[-1]):
+            break
+    return {
+        "dims": np.array(dims.as_tuple(), dtype=np.int32),
+        "states": np.stack(states),
+        "obs": np.stack(obs),
+        "actions": np.array(actions, dtype=np.int32).reshape(-1, A),
+        "rewards": np.array(rewards, dtype=np.float64).reshape(-1, A),
+        "terms": np.array(terms, dtype=np.uint8).reshape(-1, A),
+        "truncs": np.array(truncs, dtype=np.uint8).reshape(-1, A),
+        "statics": statics,
+        "class_order": slotmap.class_order,
+    }
+
+
+def episode_stats(ep):
+    """Coverage summary of what an episode reached (for the generator log)."""
+    dims = soa.Dims(*[int(v) for v in ep["dims"]])
+    last = ep["states"][-1]
+    chopped = mashed = plated = clones = 0
+    for s in range(dims.D):
+        x, y, c, f = soa.unpack_dyn0(last[dims.dyn0_word0 + s])
+        cont, seq = soa.unpack_dyn1(last[dims.dyn1_word0 + s])
+        if f & soa.DYN_ALIVE:
+            chopped += bool(f & soa.DYN_CHOPPED)
+            mashed += bool(f & soa.DYN_MASHED)
+            plated += cont >= 0
+    return dict(steps=len(ep["actions"]), chopped=chopped, mashed=mashed, plated=plated,
+                term=int(ep["terms"][-1].any()) if len(ep["terms"]) else 0,
+                ret=float(ep["rewards"].sum()) if len(ep["rewards"]) else 0.0,
+                marks=hex(int(last[soa.W_MARKS])))
+
+
+def save_set(name, cfg, episodes, out_dir):
+    """One .npz per set: episodes concatenated, with offsets."""
+    meta = dict(cfg)
+    # store level / meta names as package-relative stems (the build ships the same files)
+    meta["level"] = os.path.splitext(os.path.basename(cfg["level"]))[0]
+    meta["meta_file"] = os.path.splitext(os.path.basename(cfg["meta_file"]))[0]
+    meta["episodes"] = []
+    arrays = {}
+    for i, ep in enumerate(episodes):
+        for k in ("dims", "states", "obs", "actions", "rewards", "terms", "truncs"):
+            arrays[f"e{i}_{k}"] = ep[k]
+        meta["episodes"].append({"statics": ep["statics"], "class_order": ep["class_order"],
+                                 "seed": ep["seed"], "policy": ep["policy"] if isinstance(ep["policy"], str) else "scripted"})
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    sz = os.path.getsize(path)
+    print(f"[golden] {name}: {len(episodes)} episodes, {sum(len(e['actions']) for e in episodes)} steps, {sz / 1024:.0f} KiB")
+    return path
+
+
+# ------------------------------------------------------------------------------------------------
+# fixture sets
+# ------------------------------------------------------------------------------------------------
+
+def base_cfg(level, agents, recipes, scheme="scheme3", max_steps=400, all_dishes=False, meta="example", max_dyn=None,
+             reward_scheme=None):
+    return dict(level=level, meta_file=meta, num_agents=agents, max_steps=max_steps, recipes=recipes,
+                end_condition_all_dishes=all_dishes, action_scheme=scheme,
+                max_dyn=max_dyn if max_dyn is not None else level_max_dyn(level),
+                reward_scheme=reward_scheme)
+
+
+def run_set(name, cfg, plan, out_dir):
+    eps = []
+    for seed, policy, max_len in plan:
+        ep = capture_episode(cfg, seed, policy, max_len)
+        ep["seed"], ep["policy"] = seed, policy
+        print(f"   {name} seed={seed} policy={policy if isinstance(policy, str) else 'scripted'}: {episode_stats(ep)}")
+        eps.append(ep)
+    return save_set(name, cfg, eps, out_dir)
+
+
+def kat_c3(out_dir):
+    """SURVEY.md Appendix C.3 pinned known-answer trace (heuristic agent, completes in 30 steps)."""
+    cfg = base_cfg("coop_test", 1, ["TomatoLettuceSalad"], all_dishes=True)
+    acts = [[int(c)] for c in "312442214141113331242131124444"]
+    ep = capture_episode(cfg, 1, acts, max_len=len(acts))
+    ep["seed"], ep["policy"] = 1, "scripted"
+    assert ep["rewards"][-1, 0] == 19.9875 and ep["terms"][-1, 0] == 1
+    assert abs(ep["rewards"].sum() - 19.625) < 1e-12
+    h = hashlib.sha256()
+    for o in ep["obs"]:
+        h.update(o[0].tobytes())
+    assert h.hexdigest().startswith("24e17ccb854352dd"), h.hexdigest()
+    print("   KAT C.3 reproduced: sha256(obs) =", h.hexdigest()[:16])
+    return save_set("kat_c3", cfg, [ep], out_dir)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+
+    sets = {}
+    sets["kat_c3"] = lambda: kat_c3(args.out)
+    # cfg 1: 1 agent, coop_test, TomatoLettuceSalad
+    sets["cfg1_coop_1agent"] = lambda: run_set(
+        "cfg1_coop_1agent", base_cfg("coop_test", 1, ["TomatoLettuceSalad"]),
+        [(0, "uniform", 400), (2, "bumper", 400), (3, "heuristic", 120), (4, "heuristic", 120), (5, "bumper", 200)], args.out)
+    # cfg 2: 2 agents, coop_test, [TomatoLettuceSalad, CarrotBanana]
+    sets["cfg2_coop_2agents"] = lambda: run_set(
+        "cfg2_coop_2agents", base_cfg("coop_test", 2, ["TomatoLettuceSalad", "CarrotBanana"]),
+        [(10, "uniform", 400), (11, "bumper", 400), (12, "bumper", 400), (13, "mixed", 200), (14, "heuristic", 150),
+         (15, "mixed", 200), (16, "bumper", 300), (17, "heuristic", 150)], args.out)
+    sets["cfg2_all_dishes"] = lambda: run_set(
+        "cfg2_all_dishes", base_cfg("coop_test", 2, ["TomatoLettuceSalad", "CarrotBanana"], all_dishes=True,
+                                    reward_scheme={"recipe_reward": 20, "max_time_penalty": -5, "recipe_penalty": -40,
+                                                   "recipe_node_reward": 1.5}),
+        [(20, "heuristic", 250), (21, "mixed", 250), (22, "bumper", 250), (23, "heuristic", 250)], args.out)
+    # cfg 3 ingredients: other levels, other recipes
+    sets["coexistence_2agents"] = lambda: run_set(
+        "coexistence_2agents", base_cfg("coexistence_test", 2, ["MashedCarrotBanana", "AppleWatermelon"], max_steps=300),
+        [(30, "bumper", 300), (31, "mixed", 300), (32, "heuristic", 200), (33, "uniform", 300), (34, "bumper", 300)], args.out)
+    sets["switch_2agents"] = lambda: run_set(
+        "switch_2agents", base_cfg("switch_test", 2, ["TomatoLettuceSalad", "CarrotBanana"], max_steps=300),
+        [(40, "bumper", 300), (41, "bumper", 300), (42, "uniform", 300), (43, "mixed", 300)], args.out)
+    sets["switch_misc_recipes"] = lambda: run_set(
+        "switch_misc_recipes", base_cfg("switch_test", 2, ["TomatoSalad", "no_recipe"], max_steps=200,
+                                        reward_scheme={"recipe_reward": 10.5, "max_time_penalty": -3, "recipe_penalty": -7,
+                                                       "recipe_node_reward": 2}),
+        [(50, "bumper", 200), (51, "heuristic", 200), (52, "bumper", 200)], args.out)
+    sets["coop_onion_recipes"] = lambda: run_set(
+        "coop_onion_recipes", base_cfg("coop_test", 2, ["TomatoLettuceOnionSalad", "CucumberOnion"], max_steps=150),
+        [(60, "bumper", 150), (61, "uniform", 150)], args.out)
+    # scheme1
+    sets["scheme1_coop_2agents"] = lambda: run_set(
+        "scheme1_coop_2agents", base_cfg("coop_test", 2, ["TomatoLettuceSalad", "CarrotBanana"], scheme="scheme1", max_steps=300),
+        [(70, "bumper", 300), (71, "bumper", 300), (72, "uniform", 300), (73, "bumper", 300)], args.out)
+    sets["scheme1_switch_2agents"] = lambda: run_set(
+        "scheme1_switch_2agents", base_cfg("switch_test", 2, ["MashedCarrotBanana", "TomatoSalad"], scheme="scheme1", max_steps=300),
+        [(80, "bumper", 300), (81, "uniform", 300), (82, "bumper", 300)], args.out)
+    # truncation-heavy short episodes
+    sets["short_truncation"] = lambda: run_set(
+        "short_truncation", base_cfg("coop_test", 2, ["TomatoLettuceSalad", "CarrotBanana"], max_steps=5),
+        [(90, "uniform", 5), (91, "bumper", 5), (92, "uniform", 5)], args.out)
+    # custom levels shipped by the build (4 agents, 16x16) if present
+    lvl16 = os.path.join(REPO, "cooking_zoo_amd", "utils", "level", "large_16x16.json")
+    meta16 = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", "large_16x16.json")
+    if os.path.exists(lvl16) and os.path.exists(meta16):
+        sets["large16_4agents"] = lambda: run_set(
+            "large16_4agents",
+            base_cfg(lvl16, 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"],
+                     max_steps=250, meta=meta16),
+            [(100, "bumper", 250), (101, "bumper", 250), (102, "uniform", 250), (103, "mixed", 250)], args.out)
+        sets["large16_scheme1"] = lambda: run_set(
+            "large16_scheme1",
+            base_cfg(lvl16, 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"],
+                     scheme="scheme1", max_steps=200, meta=meta16),
+            [(110, "bumper", 200), (111, "uniform", 200)], args.out)
+    crowd = os.path.join(REPO, "cooking_zoo_amd", "utils", "level", "crowded_6x5.json")
+    metac = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", "crowded_6x5.json")
+    if os.path.exists(crowd) and os.path.exists(metac):
+        sets["crowded_4agents"] = lambda: run_set(
+            "crowded_4agents",
+            base_cfg(crowd, 4, ["TomatoSalad", "TomatoLettuceSalad", "no_recipe", "MashedCarrotBanana"], max_steps=200, meta=metac),
+            [(120, "uniform", 200), (121, "uniform", 200), (122, "bumper", 200), (123, "bumper", 200)], args.out)
+        sets["crowded_scheme1"] = lambda: run_set(
+            "crowded_scheme1",
+            base_cfg(crowd, 4, ["TomatoSalad", "TomatoLettuceSalad", "no_recipe", "MashedCarrotBanana"], scheme="scheme1",
+                     max_steps=200, meta=metac),
+            [(130, "uniform", 200), (131, "bumper", 200)], args.out)
+
+    for name, fn in sets.items():
+        if args.only and args.only != name:
+            continue
+        fn()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Author the build's level / meta JSON files (schema: SURVEY.md Appendix B.3).
+
+* large_16x16  : BASELINE config 5 (16x16, 4 agents, max object density).
+* crowded_6x5  : tiny 4-agent level with a Switch and a Block (collision chains, shared cells).
+* coop_test / coexistence_test / switch_test / example meta: the levels every BASELINE config names.
+  They are *input data* of the path (a caller passes level="coop_test"); when /root/reference is
+  present they are re-serialised from the parsed JSON so the layouts are identical by construction.
+"""
+import json
+import os
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LEVEL_DIR = os.path.join(REPO, "cooking_zoo_amd", "utils", "level")
+META_DIR = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files")
+REF = "/root/reference/cooking_zoo/utils"
+
+
+def dump_level(path, lv):
+    with open(path, "w") as f:
+        f.write("{\n")
+        f.write('"LEVEL_LAYOUT": %s,\n' % json.dumps(lv["LEVEL_LAYOUT"]))
+        for key in ("STATIC_OBJECTS", "DYNAMIC_OBJECTS", "AGENTS", "DYNAMIC_EXCLUDED_POSITIONS"):
+            f.write('"%s": [\n' % key)
+            f.write(",\n".join("    " + json.dumps(e) for e in lv[key]))
+            f.write("\n]%s\n" % ("" if key == "DYNAMIC_EXCLUDED_POSITIONS" else ","))
+        f.write("}\n")
+
+
+def dump_meta(path, meta):
+    with open(path, "w") as f:
+        f.write("[\n" + ",\n".join("    " + json.dumps(e) for e in meta) + "\n]\n")
+
+
+def large_16x16():
+    W = H = 16
+    rows = []
+    for y in range(H):
+        row = ""
+        for x in range(W):
+            border = x in (0, W - 1) or y in (0, H - 1)
+            column = x in (3, 6, 9, 12) and 2 <= y <= 13
+            row += "-" if (border or column) else " "
+        rows.append(row)
+    one = lambda name, x, y: {name: {"COUNT": 1, "X_POSITION": [x], "Y_POSITION": [y]}}
+    statics = [one("Cutboard", x, y) for x, y in [(3, 4), (3, 11), (6, 6), (6, 9), (9, 6), (9, 9), (12, 4), (12, 11)]]
+    statics += [one("Blender", x, y) for x, y in [(0, 5), (0, 10), (15, 5), (15, 10)]]
+    statics += [{"Deliversquare": {"COUNT": 4, "X_POSITION": [4, 7, 8, 11], "Y_POSITION": [0]}}]
+    allx, ally = list(range(W)), list(range(H))
+    dyn = [{name: {"COUNT": 8, "X_POSITION": allx, "Y_POSITION": ally}}
+           for name in ["Plate", "Tomato", "Onion", "Lettuce", "Carrot", "Banana", "Apple", "Watermelon",
+                        "Cucumber", "Bread"]]
+    agents = [{"MAX_COUNT": 1, "X_POSITION": [1, 2], "Y_POSITION": list(range(1, 15))},
+              {"MAX_COUNT": 1, "X_POSITION": [13, 14], "Y_POSITION": list(range(1, 15))},
+              {"MAX_COUNT": 1, "X_POSITION": [4, 5, 7, 8], "Y_POSITION": list(range(1, 15))},
+              {"MAX_COUNT": 1, "X_POSITION": [10, 11], "Y_POSITION": list(range(1, 15))}]
+    lv = {"LEVEL_LAYOUT": "\n".join(rows), "STATIC_OBJECTS": statics, "DYNAMIC_OBJECTS": dyn, "AGENTS": agents,
+          "DYNAMIC_EXCLUDED_POSITIONS": [[0, 0], [15, 0], [0, 15], [15, 15]]}
+    meta = [{"Cutboard": 8}, {"Counter": 108}, {"Blender": 4}, {"Deliversquare": 4}, {"Plate": 8}, {"Tomato": 8},
+            {"Onion": 8}, {"Lettuce": 8}, {"Carrot": 8}, {"Banana": 8}, {"Apple": 8}, {"Watermelon": 8},
+            {"Cucumber": 8}, {"Bread": 16}, {"Agent": 4}]
+    return lv, meta
+
+
+def crowded_6x5():
+    rows = ["------", "-    -", "-    -", "-    -", "------"]
+    one = lambda name, x, y: {name: {"COUNT": 1, "X_POSITION": [x], "Y_POSITION": [y]}}
+    statics = [one("Cutboard", 0, 2), one("Deliversquare", 3, 0), one("Blender", 5, 2),
+               one("Switch", 2, 2), one("Block", 3, 2)]
+    dyn = [one("Plate", 1, 0), one("Tomato", 0, 1), one("Carrot", 5, 3), one("Bread", 2, 4),
+           {"Lettuce": {"COUNT": 1, "X_POSITION": [1, 2, 3, 4], "Y_POSITION": [0, 4], "OPTIONAL": 0.5}}]
+    cells = {"X_POSITION": [1, 2, 3, 4], "Y_POSITION": [1, 2, 3]}
+    agents = [dict(MAX_COUNT=1, **cells) for _ in range(4)]
+    lv = {"LEVEL_LAYOUT": "\n".join(rows), "STATIC_OBJECTS": statics, "DYNAMIC_OBJECTS": dyn, "AGENTS": agents,
+          "DYNAMIC_EXCLUDED_POSITIONS": [[0, 0], [5, 0], [0, 4], [5, 4]]}
+    meta = [{"Agent": 4}, {"Switch": 1}, {"Block": 1}, {"Cutboard": 1}, {"Counter": 18}, {"Blender": 1},
+            {"Deliversquare": 1}, {"Bread": 2}, {"Plate": 1}, {"Tomato": 1}, {"Carrot": 1}, {"Lettuce": 1}]
+    return lv, meta
+
+
+def main():
+    os.makedirs(LEVEL_DIR, exist_ok=True)
+    os.makedirs(META_DIR, exist_ok=True)
+    lv, meta = large_16x16()
+    dump_level(os.path.join(LEVEL_DIR, "large_16x16.json"), lv)
+    dump_meta(os.path.join(META_DIR, "large_16x16.json"), meta)
+    lv, meta = crowded_6x5()
+    dump_level(os.path.join(LEVEL_DIR, "crowded_6x5.json"), lv)
+    dump_meta(os.path.join(META_DIR, "crowded_6x5.json"), meta)
+    if os.path.isdir(REF):
+        for name in ("coop_test", "coexistence_test", "switch_test"):
+            with open(os.path.join(REF, "level", name + ".json")) as f:
+                dump_level(os.path.join(LEVEL_DIR, name + ".json"), json.load(f))
+        with open(os.path.join(REF, "meta_files", "example.json")) as f:
+            dump_meta(os.path.join(META_DIR, "example.json"), json.load(f))
+
+
+if __name__ == "__main__":
+    main()
