@@ -1,0 +1,102 @@
+"""ctypes binding of include/cookingzoo.h (libcookingzoo_hip.so).
+
+The product path has no CPU fallback: if the HIP library is missing or no GPU is visible, creating an
+environment raises.  (Pure-data modules such as soa.py / layout.py import without it.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcookingzoo_hip.so")
+
+
+class CzConfig(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_agents", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("max_dyn", C.c_int32), ("feat_len", C.c_int32), ("action_scheme", C.c_int32),
+                ("max_steps", C.c_int32), ("end_condition_all", C.c_int32), ("num_recipes", C.c_int32),
+                ("auto_reset", C.c_int32), ("device_id", C.c_int32), ("env_id_base", C.c_int64),
+                ("recipe_reward", C.c_double), ("max_time_penalty", C.c_double), ("recipe_penalty", C.c_double),
+                ("recipe_node_reward", C.c_double)]
+
+
+class CzStats(C.Structure):
+    _fields_ = [("env_steps", C.c_uint64), ("episodes", C.c_uint64), ("length_sum", C.c_uint64),
+                ("truncations", C.c_uint64), ("terminations", C.c_uint64), ("recipes_completed", C.c_uint64 * 4),
+                ("return_sum", C.c_double * 4)]
+
+    def as_dict(self):
+        return {"env_steps": int(self.env_steps), "episodes": int(self.episodes), "length_sum": int(self.length_sum),
+                "truncations": int(self.truncations), "terminations": int(self.terminations),
+                "recipes_completed": [int(v) for v in self.recipes_completed],
+                "return_sum": [float(v) for v in self.return_sum]}
+
+
+# every symbol include/cookingzoo.h declares: (name, restype, argtypes)
+_VP, _I32, _I64, _U32, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
+SYMBOLS = [
+    ("cz_create", C.c_int, [C.POINTER(CzConfig), C.POINTER(_VP)]),
+    ("cz_destroy", C.c_int, [_VP]),
+    ("cz_last_error", C.c_char_p, [_VP]),
+    ("cz_record_words", _I32, [_VP]),
+    ("cz_abi_version", _I32, []),
+    ("cz_sizeof_config", _I32, []),
+    ("cz_sizeof_stats", _I32, []),
+    ("cz_sync", C.c_int, [_VP]),
+    ("cz_load_recipes", C.c_int, [_VP, _VP, _I32]),
+    ("cz_load_layouts", C.c_int, [_VP, _VP, _VP, _I32]),
+    ("cz_set_state", C.c_int, [_VP, _I64, _I64, _VP]),
+    ("cz_get_state", C.c_int, [_VP, _I64, _I64, _VP]),
+    ("cz_reset", C.c_int, [_VP, _I64, _I64, _VP, _VP, _VP, _VP]),
+    ("cz_observe", C.c_int, [_VP, _I64, _I64, _VP]),
+    ("cz_step", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    ("cz_step_device", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    ("cz_rollout", C.c_int, [_VP, _I32, _U64, _U32, _VP, _VP, _VP, _VP]),
+    ("cz_action", _U32, [_U64, _I64, _I32, _U32, _U32]),
+    ("cz_next_layout", _U32, [_I64, _U32, _U32, _U32]),
+    ("cz_dev_alloc", _VP, [_VP, C.c_size_t]),
+    ("cz_dev_free", C.c_int, [_VP, _VP]),
+    ("cz_memcpy_h2d", C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    ("cz_memcpy_d2h", C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    ("cz_timer_start", C.c_int, [_VP]),
+    ("cz_timer_stop", C.c_int, [_VP, C.POINTER(C.c_float)]),
+    ("cz_kernel_time_reset", C.c_int, [_VP, _I32]),
+    ("cz_kernel_time_read", C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(_I64)]),
+    ("cz_get_stats", C.c_int, [_VP, C.POINTER(CzStats)]),
+    ("cz_reset_stats", C.c_int, [_VP]),
+    ("cz_comm_unique_id", C.c_int, [_VP]),
+    ("cz_comm_init", C.c_int, [_VP, _I32, _I32, _VP]),
+    ("cz_stats_allgather", C.c_int, [_VP, _VP]),
+]
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libcookingzoo_hip.so (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              f"or `make -C cooking_zoo_amd/csrc` (hipcc --offload-arch=gfx950). "
+                              f"cooking_zoo_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.cz_sizeof_config() != C.sizeof(CzConfig) or L.cz_sizeof_stats() != C.sizeof(CzStats):
+            raise NativeError("libcookingzoo_hip.so and cooking_zoo_amd/_native.py disagree on struct layouts")
+        _lib = L
+    return _lib
+
+
+def check(handle, rc):
+    if rc != 0:
+        msg = lib().cz_last_error(handle)
+        raise NativeError(msg.decode() if msg else f"libcookingzoo_hip error {rc}")

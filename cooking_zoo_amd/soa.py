@@ -13,7 +13,9 @@ Per-env *record* (array of little-endian u32 words, `record_words(cfg)` long):
   word 3      status                 bit0 = episode over (terminated|truncated), awaiting reset
   word 4      episode                episodes completed by this env slot
   word 5      recipe ids             4 x u8, index into the recipe table, 0xFF = unused
-  word 6,7    reserved
+  word 6      layout pool            base | count<<16: the slice of the layout pool this env redraws from on
+                                     auto-reset (0 = whole pool); lets one batch mix levels
+  word 7      reserved
   word 8..11  agents[4]              x | y<<8 | orientation<<16 | (held slot+1)<<24   world_objects.py:776-783
   then        cells[CW]              W*H bytes, 4 per word:  type | READY<<3 | TOGGLE<<4 | ACTIVE<<5 | WALK<<6
   then        dyn0[D]                x | y<<8 | cls<<16 | flags<<24
@@ -64,9 +66,9 @@ MAX_AGENTS = 4
  OP_AG_O1, OP_AG_O2, OP_AG_O3, OP_AG_O4, OP_AG_ONE) = range(20)
 
 HDR_WORDS = 8
-W_T, W_MARKS, W_LAYOUT, W_STATUS, W_EPISODE, W_RECIPES, W_RES0, W_RES1 = range(8)
+W_T, W_MARKS, W_LAYOUT, W_STATUS, W_EPISODE, W_RECIPES, W_POOL, W_RES1 = range(8)
 AGENT_WORD0 = HDR_WORDS
-STATUS_DONE = 1
+STATUS_DONE, STATUS_TERM, STATUS_TRUNC = 1, 2, 4
 
 
 def class_node_id(name: str) -> int:

@@ -1,0 +1,243 @@
+"""CookingVecEnv: N independent CookingZoo worlds advanced by one HIP grid launch per step.
+
+This is the batched form of the reference's `CookingEnvironment` (environment/cooking_env.py:49-385):
+same kwargs (level, meta_file, num_agents, max_steps, recipes, end_condition_all_dishes, action_scheme,
+reward_scheme), plus the batch geometry.  All world state lives in HBM behind the C-ABI of
+include/cookingzoo.h; this class only prepares tables (layout pool, recipe tables) and moves arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import random as _random
+
+import numpy as np
+
+from cooking_zoo_amd import _native, soa
+from cooking_zoo_amd.cooking_book import recipe_drawer
+from cooking_zoo_amd.cooking_world.actions import ACTION_SCHEMES
+from cooking_zoo_amd.cooking_world.engine import load_level as _ll
+from cooking_zoo_amd.cooking_world.layout import feature_length
+
+DEFAULT_REWARD_SCHEME = {"recipe_reward": 20, "max_time_penalty": -5, "recipe_penalty": -40, "recipe_node_reward": 0}
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class DeviceBuffer:
+    """A typed HBM allocation owned by a CookingVecEnv (no torch involved)."""
+
+    def __init__(self, env, shape, dtype):
+        self.env, self.shape, self.dtype = env, tuple(int(s) for s in shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = _native.lib().cz_dev_alloc(env._h, self.nbytes)
+        if not self.ptr:
+            _native.check(env._h, 1)
+
+    def to_host(self, out=None):
+        out = np.empty(self.shape, self.dtype) if out is None else out
+        _native.check(self.env._h, _native.lib().cz_memcpy_d2h(self.env._h, _ptr(out), self.ptr, self.nbytes))
+        return out
+
+    def from_host(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert arr.nbytes == self.nbytes
+        _native.check(self.env._h, _native.lib().cz_memcpy_h2d(self.env._h, self.ptr, _ptr(arr), self.nbytes))
+
+    def free(self):
+        if self.ptr:
+            _native.lib().cz_dev_free(self.env._h, self.ptr)
+            self.ptr = None
+
+
+def resolve_recipe_tables(recipes):
+    """-> (registry dict, names list).  Same rule as cooking_env.py:100-105: a non-empty user
+    RECIPE_STORE replaces the default book."""
+    book = recipe_drawer.RECIPE_STORE if recipe_drawer.RECIPE_STORE else recipe_drawer.RECIPES
+    return book, list(book.keys())
+
+
+class CookingVecEnv:
+    def __init__(self, num_envs, level, meta_file, num_agents, max_steps, recipes, end_condition_all_dishes=False,
+                 action_scheme="scheme1", reward_scheme=None, *, num_layouts=256, layout_seed=0, layouts=None,
+                 auto_reset=True, device_id=0, env_id_base=0, max_dyn=None):
+        """`level` may be one level name/path or a list (env e uses levels[e % len]); `recipes` is a list of
+        names (every env the same) or an int array [num_envs, R] of indices into the recipe book.
+        `layouts` (optional) supplies pre-instantiated Layout objects per level instead of drawing
+        `num_layouts` of them with random.Random(layout_seed)."""
+        if action_scheme not in ACTION_SCHEMES:
+            raise ValueError("action_scheme must be 'scheme1' or 'scheme3' (scheme2 raises AttributeError in the "
+                             "reference: action_scheme2.py:15)")
+        self.num_envs, self.num_agents, self.max_steps = int(num_envs), int(num_agents), int(max_steps)
+        self.action_scheme = action_scheme
+        self.scheme_class = ACTION_SCHEMES[action_scheme]
+        self.n_actions = len(self.scheme_class.ACTIONS)
+        self.meta = _ll.load_meta_file(meta_file)
+        assert self.num_agents <= self.meta["Agent"], "Too many agents for this level"      # cooking_env.py:93
+        self.levels = [level] if isinstance(level, str) else list(level)
+        self.level_objects = [_ll.load_level_file(l) for l in self.levels]
+        self.reward_scheme = dict(reward_scheme or DEFAULT_REWARD_SCHEME)
+        self.end_condition_all_dishes = bool(end_condition_all_dishes)
+        self.F = feature_length(self.meta)
+
+        # ---- recipe tables
+        self.book, self.book_names = resolve_recipe_tables(recipes)
+        self.recipe_table = np.stack([self.book[n]().flatten() for n in self.book_names])
+        if isinstance(recipes, np.ndarray):
+            rid = np.asarray(recipes, dtype=np.int64)
+            assert rid.shape[0] == self.num_envs
+            self.recipe_names = None
+        else:
+            self.recipe_names = list(recipes)
+            rid = np.tile(np.array([self.book_names.index(r) for r in recipes], dtype=np.int64), (self.num_envs, 1))
+        self.num_recipes = rid.shape[1]
+        if not (self.num_agents <= self.num_recipes <= soa.MAX_RECIPES_PER_ENV):
+            raise ValueError("need one recipe per agent and at most 4 recipes (cooking_env.py:329)")
+        self.recipe_ids = np.full((self.num_envs, 4), 0xFF, dtype=np.uint8)
+        self.recipe_ids[:, :self.num_recipes] = rid
+
+        # ---- layout pool (per level a contiguous slice)
+        rng = _random.Random(layout_seed)
+        self.layouts = []
+        self.pool_slices = []
+        for li, lv in enumerate(self.level_objects):
+            base = len(self.layouts)
+            if layouts is not None:
+                mine = layouts[li] if isinstance(layouts[0], (list, tuple)) else layouts
+            else:
+                mine = [_ll.instantiate(lv, self.meta, self.num_agents, rng) for _ in range(int(num_layouts))]
+            self.layouts += list(mine)
+            self.pool_slices.append((base, len(mine)))
+        W, H = self.layouts[0].width, self.layouts[0].height
+        if any((l.width, l.height) != (W, H) for l in self.layouts):
+            raise ValueError("all levels of one batch must share the grid size")
+        D = max_dyn if max_dyn is not None else max(max(_ll.level_max_dyn(lv) for lv in self.level_objects),
+                                                    max(l.slots_used for l in self.layouts))
+        self.dims = soa.Dims(W, H, max(1, D), self.num_agents, self.F)
+
+        # ---- device handle
+        L = _native.lib()
+        rs = self.reward_scheme
+        self._cfg = _native.CzConfig(self.num_envs, self.num_agents, W, H, self.dims.D, self.F, self.scheme_class.CODE,
+                                     self.max_steps, int(self.end_condition_all_dishes), self.num_recipes,
+                                     int(bool(auto_reset)), int(device_id), int(env_id_base),
+                                     float(rs["recipe_reward"]), float(rs["max_time_penalty"]),
+                                     float(rs["recipe_penalty"]), float(rs["recipe_node_reward"]))
+        h = C.c_void_p()
+        rc = L.cz_create(C.byref(self._cfg), C.byref(h))
+        if rc != 0:
+            raise _native.NativeError((L.cz_last_error(None) or b"cz_create failed").decode())
+        self._h = h
+        self.env_id_base = int(env_id_base)
+        assert L.cz_record_words(self._h) == self.dims.RW
+        _native.check(self._h, L.cz_load_recipes(self._h, _ptr(self.recipe_table), len(self.book_names)))
+        self._upload_layouts()
+        self._buffers = []
+        self.env_level = np.arange(self.num_envs) % len(self.levels)
+
+    # ------------------------------------------------------------------ tables
+    def _upload_layouts(self):
+        recs = np.stack([l.init_record(self.dims, i) for i, l in enumerate(self.layouts)])
+        desc = np.stack([l.obs_descriptor(self.meta, self.dims) for l in self.layouts])
+        self._lay_records, self._lay_desc = recs, desc
+        _native.check(self._h, _native.lib().cz_load_layouts(self._h, _ptr(recs), _ptr(desc), len(self.layouts)))
+
+    def set_layouts(self, layouts):
+        """Replace the whole pool (single-level batches; used by the single-env facade at reset)."""
+        self.layouts = list(layouts)
+        self.pool_slices = [(0, len(self.layouts))]
+        self._upload_layouts()
+
+    # ------------------------------------------------------------------ reset / step
+    def initial_layout_ids(self):
+        """Episode-0 layout of every env: the same keyed draw auto-reset uses (shard invariant)."""
+        ids = np.empty(self.num_envs, dtype=np.int32)
+        pools = np.empty(self.num_envs, dtype=np.uint32)
+        L = _native.lib()
+        for e in range(self.num_envs):
+            base, count = self.pool_slices[self.env_level[e]]
+            pools[e] = base | (count << 16)
+            ids[e] = L.cz_next_layout(self.env_id_base + e, 0, int(pools[e]), len(self.layouts))
+        return ids, pools
+
+    def reset(self, layout_ids=None, return_obs=True, env_begin=0, env_count=None):
+        n = self.num_envs if env_count is None else int(env_count)
+        ids, pools = self.initial_layout_ids()
+        if layout_ids is not None:
+            ids = np.ascontiguousarray(layout_ids, dtype=np.int32)
+        else:
+            ids = ids[env_begin:env_begin + n].copy()
+        pools = np.ascontiguousarray(pools[env_begin:env_begin + n])
+        obs = np.empty((n, self.num_agents, self.F), dtype=np.float64) if return_obs else None
+        rid = np.ascontiguousarray(self.recipe_ids[env_begin:env_begin + n])
+        _native.check(self._h, _native.lib().cz_reset(self._h, env_begin, n, _ptr(ids), _ptr(rid), _ptr(pools), _ptr(obs)))
+        return obs
+
+    def step(self, actions, return_obs=True):
+        """actions int [N, A] -> (obs f64 [N, A, F] | None, rewards f64 [N, A], terminations u8, truncations u8)."""
+        acts = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.num_envs, self.num_agents)
+        N, A = self.num_envs, self.num_agents
+        obs = np.empty((N, A, self.F), dtype=np.float64) if return_obs else None
+        rew = np.empty((N, A), dtype=np.float64)
+        term = np.empty((N, A), dtype=np.uint8)
+        trunc = np.empty((N, A), dtype=np.uint8)
+        _native.check(self._h, _native.lib().cz_step(self._h, _ptr(acts), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc)))
+        return obs, rew, term, trunc
+
+    def observe(self, env_begin=0, env_count=None):
+        n = self.num_envs if env_count is None else int(env_count)
+        obs = np.empty((n, self.num_agents, self.F), dtype=np.float64)
+        _native.check(self._h, _native.lib().cz_observe(self._h, env_begin, n, _ptr(obs)))
+        return obs
+
+    # ------------------------------------------------------------------ device-resident API
+    def alloc(self, shape, dtype):
+        b = DeviceBuffer(self, shape, dtype)
+        self._buffers.append(b)
+        return b
+
+    def step_device(self, d_actions, d_obs, d_rewards, d_term, d_trunc):
+        p = lambda b: b.ptr if b is not None else None
+        _native.check(self._h, _native.lib().cz_step_device(self._h, p(d_actions), p(d_obs), p(d_rewards), p(d_term),
+                                                            p(d_trunc)))
+
+    def rollout(self, T, seed, step0=0, d_obs=None, d_rewards=None, d_term=None, d_trunc=None):
+        p = lambda b: b.ptr if b is not None else None
+        _native.check(self._h, _native.lib().cz_rollout(self._h, int(T), int(seed), int(step0), p(d_obs), p(d_rewards),
+                                                        p(d_term), p(d_trunc)))
+
+    def sync(self):
+        _native.check(self._h, _native.lib().cz_sync(self._h))
+
+    # ------------------------------------------------------------------ state / stats
+    def get_state(self, env_begin=0, env_count=None):
+        n = self.num_envs if env_count is None else int(env_count)
+        recs = np.empty((n, self.dims.RW), dtype=np.uint32)
+        _native.check(self._h, _native.lib().cz_get_state(self._h, env_begin, n, _ptr(recs)))
+        return recs
+
+    def set_state(self, records, env_begin=0):
+        recs = np.ascontiguousarray(records, dtype=np.uint32).reshape(-1, self.dims.RW)
+        _native.check(self._h, _native.lib().cz_set_state(self._h, env_begin, recs.shape[0], _ptr(recs)))
+
+    def stats(self):
+        st = _native.CzStats()
+        _native.check(self._h, _native.lib().cz_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def reset_stats(self):
+        _native.check(self._h, _native.lib().cz_reset_stats(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for b in self._buffers:
+                b.free()
+            _native.lib().cz_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

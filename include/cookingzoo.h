@@ -1,0 +1,151 @@
+/*
+ * cookingzoo.h -- C-ABI of the MI355X-native CookingZoo step() path (libcookingzoo_hip.so).
+ *
+ * The reference (DavidRother/cooking_zoo) has no FFI: its boundary is the Python API
+ * (`cooking_zoo/environment/cooking_env.py:26-46` parallel_env, `:243` accumulated_step, `:271` observe,
+ * `:178` reset).  This header is the boundary the build introduces UNDER that API: plain pointers and
+ * sizes, no torch types.  Each entry point names the reference code it replaces.  The Python host
+ * (cooking_zoo_amd/_native.py) binds it with ctypes; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure with a message available from
+ * cz_last_error(handle) (or cz_last_error(NULL) for creation failures).  One host thread per handle;
+ * one HIP stream per handle; the caller owns every buffer it passes; the library owns device state
+ * until cz_destroy.  "d_" parameters are device pointers (from cz_dev_alloc or any HIP allocation).
+ *
+ * Per-env state travels as a flat "record" of cz_record_words() little-endian uint32 words:
+ *   word 0 t | 1 recipe-node marks (bit 8r+j) | 2 layout id | 3 status (1 done, 2 terminated, 4 truncated)
+ *   | 4 episode | 5 recipe ids (4 x u8) | 6 layout-pool slice (base | count<<16) | 7 reserved | 8..11 agents (x | y<<8 | orientation<<16 | (held slot+1)<<24)
+ *   | cells (W*H bytes: type | READY<<3 | TOGGLE<<4 | ACTIVE<<5 | WALK<<6) | dyn0[D] (x | y<<8 | class<<16 | flags<<24;
+ *   flags: 1 alive, 2 chopped, 4 mashed, 8 free) | dyn1[D] ((plate slot+1) | seq<<8), padded to 16 words.
+ * (normative description: cooking_zoo_amd/soa.py)
+ */
+#ifndef COOKINGZOO_H
+#define COOKINGZOO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cz_handle_s *cz_handle;
+
+/* Batch configuration.  Mirrors the kwargs of CookingEnvironment.__init__ (cooking_env.py:62-64) that
+ * reach the step path, plus the batch geometry. */
+typedef struct cz_config {
+    int32_t num_envs;            /* env instances owned by this handle (one wavefront each)          */
+    int32_t num_agents;          /* A <= 4            (cooking_env.py:76, COLORS cooking_world.py:21) */
+    int32_t width, height;       /* grid, W,H <= 32 and W*H <= 256 (parsing.py:17-18)                 */
+    int32_t max_dyn;             /* D dynamic-object slots per env, <= 128                            */
+    int32_t feat_len;            /* F features per agent (cooking_env.py:114-117)                     */
+    int32_t action_scheme;       /* 1 or 3            (cooking_env.py:60; scheme2 is dead upstream)   */
+    int32_t max_steps;           /* truncation horizon (cooking_env.py:333-334)                       */
+    int32_t end_condition_all;   /* end_condition_all_dishes (cooking_env.py:310-313)                 */
+    int32_t num_recipes;         /* recipe graphs per env, num_agents <= R <= 4 (cooking_env.py:106)  */
+    int32_t auto_reset;          /* 0: finished envs freeze until cz_reset; 1: the step after `done`
+                                    re-instantiates the env from the layout pool (next-step autoreset) */
+    int32_t device_id;           /* HIP device ordinal                                                */
+    int64_t env_id_base;         /* global id of env 0 of this handle (shard offset; keys layout draws
+                                    and the on-device action stream so results do not depend on sharding) */
+    double recipe_reward, max_time_penalty, recipe_penalty, recipe_node_reward;   /* cooking_env.py:79-80 */
+} cz_config;
+
+/* Episode statistics of one handle (one GPU): what the reference reports through `infos`
+ * (cooking_env.py:248,264,329), aggregated on the device. */
+typedef struct cz_stats {
+    uint64_t env_steps;              /* world steps executed (reset passes excluded)   */
+    uint64_t episodes;               /* episodes finished                              */
+    uint64_t length_sum;             /* sum of finished-episode lengths                */
+    uint64_t truncations;            /* episodes that ended by t >= max_steps          */
+    uint64_t terminations;           /* episodes that ended by recipe completion       */
+    uint64_t recipes_completed[4];   /* per agent slot: episodes ending with its recipe complete */
+    double return_sum[4];            /* per agent slot: sum of finished-episode returns */
+} cz_stats;
+
+/* ---- lifetime ------------------------------------------------------------------------------------- */
+int cz_create(const cz_config *cfg, cz_handle *out);
+int cz_destroy(cz_handle h);
+const char *cz_last_error(cz_handle h);
+int32_t cz_record_words(cz_handle h);
+int32_t cz_abi_version(void);
+int32_t cz_sizeof_config(void);                           /* sizeof(cz_config), for binding self-checks */
+int32_t cz_sizeof_stats(void);
+int cz_sync(cz_handle h);                                  /* wait for the handle's stream */
+
+/* ---- tables ---------------------------------------------------------------------------------------- */
+/* Recipe graphs: replaces RECIPES[name]() / Recipe.node_list (recipe_drawer.py:109-118, recipe.py:29-34).
+ * table[n][9]: word 0 = node count (<= 8); then per node (root first, node_list order)
+ *   class | condition<<8 | child-mask<<16 | counts-in-goal-sum<<24
+ *   class: 0..6 static type, 16..25 dynamic class, 255 none; condition: 0 none, 1 chopped, 2 mashed,
+ *   3 not chopped, 4 not mashed. */
+int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n_recipes);
+
+/* Layout pool: replaces load_level / parsing (load_level.py:55-71, parsing.py:5-151) results.  Per layout:
+ * its initial record (cz_record_words words; t, marks, status ignored) and its observation descriptor
+ * (feat_len words, op | ref<<8; ops listed in cooking_zoo_amd/soa.py) which encodes the meta-file class
+ * order and per-class list order that get_feature_vector (cooking_env.py:352-373) iterates. */
+int cz_load_layouts(cz_handle h, const uint32_t *init_records, const uint32_t *obs_desc, int32_t n_layouts);
+
+/* ---- state ----------------------------------------------------------------------------------------- */
+int cz_set_state(cz_handle h, int64_t env_begin, int64_t env_count, const uint32_t *records);
+int cz_get_state(cz_handle h, int64_t env_begin, int64_t env_count, uint32_t *records);
+
+/* reset(): cooking_env.py:178-210.  Re-instantiates envs [env_begin, env_begin+env_count) from
+ * layout_ids[i], assigns recipe_ids[i][0..3] (0xFF = unused) and pool_words[i] (base | count<<16: the slice of
+ * the layout pool the env redraws from under auto_reset; NULL = whole pool), evaluates the recipe marks of the
+ * fresh world (cooking_env.py:197-198) and, if obs != NULL (host, [env_count][A][F] float64), returns observe(). */
+int cz_reset(cz_handle h, int64_t env_begin, int64_t env_count, const int32_t *layout_ids,
+             const uint8_t *recipe_ids, const uint32_t *pool_words, double *obs);
+
+/* observe() (cooking_env.py:271,352-373) of the current state of envs [env_begin, env_begin+env_count):
+ * host buffer [env_count][A][F] float64. */
+int cz_observe(cz_handle h, int64_t env_begin, int64_t env_count, double *obs);
+
+/* ---- step ------------------------------------------------------------------------------------------ */
+/* One batched env step = accumulated_step (cooking_env.py:243-269): world_step (cooking_world.py:104-112),
+ * compute_rewards (cooking_env.py:290-315), compute_truncated (:333-350), then observe (:271, :352-373).
+ * Host-pointer form: actions int32 [N][A]; outputs obs float64 [N][A][F] (may be NULL), rewards float64 [N][A],
+ * terminations / truncations uint8 [N][A].  Synchronous. */
+int cz_step(cz_handle h, const int32_t *actions, double *obs, double *rewards, uint8_t *terminations,
+            uint8_t *truncations);
+
+/* Device-pointer form, asynchronous on the handle's stream (d_obs may be NULL: encode skipped). */
+int cz_step_device(cz_handle h, const int32_t *d_actions, double *d_obs, double *d_rewards,
+                   uint8_t *d_terminations, uint8_t *d_truncations);
+
+/* T fused steps in one launch with on-device uniform random actions (counter-based stream keyed by
+ * (seed, global env id, agent, step0 + t)); state stays in registers between steps.  d_obs, if not NULL,
+ * is a trajectory buffer [T][N][A][F]; d_rewards [T][N][A]; d_term/d_trunc [T][N][A] (each may be NULL
+ * to keep only device-side statistics).  Asynchronous. */
+int cz_rollout(cz_handle h, int32_t T, uint64_t seed, uint32_t step0, double *d_obs, double *d_rewards,
+               uint8_t *d_terminations, uint8_t *d_truncations);
+
+/* the action the on-device stream draws (host mirror, for parity tests) */
+uint32_t cz_action(uint64_t seed, int64_t env_global, int32_t agent, uint32_t step, uint32_t n_actions);
+/* the layout an env draws for its k-th episode under auto_reset */
+uint32_t cz_next_layout(int64_t env_global, uint32_t episode, uint32_t pool_word, uint32_t n_layouts);
+
+/* ---- device memory + timing helpers (so the Python host needs no torch) ----------------------------- */
+void *cz_dev_alloc(cz_handle h, size_t bytes);
+int cz_dev_free(cz_handle h, void *d_ptr);
+int cz_memcpy_h2d(cz_handle h, void *d_dst, const void *src, size_t bytes);
+int cz_memcpy_d2h(cz_handle h, void *dst, const void *d_src, size_t bytes);
+int cz_timer_start(cz_handle h);                           /* hipEventRecord on the handle's stream */
+int cz_timer_stop(cz_handle h, float *elapsed_ms);         /* record + synchronize + elapsed        */
+/* brackets every kernel launch of the step path with HIP events and accumulates device time */
+int cz_kernel_time_reset(cz_handle h, int32_t enable);
+int cz_kernel_time_read(cz_handle h, double *total_ms, int64_t *launches);
+
+/* ---- statistics + multi-GPU ------------------------------------------------------------------------- */
+int cz_get_stats(cz_handle h, cz_stats *out);              /* device reduction over this handle's envs */
+int cz_reset_stats(cz_handle h);
+/* RCCL over xGMI: the only collective of the path is an all-gather of one cz_stats per rank. */
+int cz_comm_unique_id(uint8_t id[128]);
+int cz_comm_init(cz_handle h, int32_t n_ranks, int32_t rank, const uint8_t id[128]);
+int cz_stats_allgather(cz_handle h, cz_stats *out /* [n_ranks] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COOKINGZOO_H */

@@ -34,7 +34,7 @@ enum { PLATE, ONION, TOMATO, LETTUCE, CARROT, CUCUMBER, BANANA, APPLE, WATERMELO
 enum { CELL_READY = 8, CELL_TOGGLE = 16, CELL_ACTIVE = 32, CELL_WALK = 64 };
 enum { DYN_ALIVE = 1, DYN_CHOPPED = 2, DYN_MASHED = 4, DYN_FREE = 8 };
 enum { COND_NONE, COND_CHOPPED, COND_MASHED, COND_NOT_CHOPPED, COND_NOT_MASHED };
-enum { W_T, W_MARKS, W_LAYOUT, W_STATUS, W_EPISODE, W_RECIPES, W_RES0, W_RES1, HDR_WORDS };
+enum { W_T, W_MARKS, W_LAYOUT, W_STATUS, W_EPISODE, W_RECIPES, W_POOL, W_RES1, HDR_WORDS };
 enum { STATUS_DONE = 1, STATUS_TERM = 2, STATUS_TRUNC = 4 };
 
 typedef struct {
@@ -710,9 +710,11 @@ static void recompute_marks(const czo_ctx *cx, World *w, uint32_t *rec)
 }
 
 /* layout an env draws for its k-th episode; keyed by the GLOBAL env id so sharding does not change results */
-uint32_t czo_next_layout(int64_t env_global, uint32_t episode, uint32_t num_layouts)
+uint32_t czo_next_layout(int64_t env_global, uint32_t episode, uint32_t pool_word, uint32_t num_layouts)
 {
-    return (uint32_t)(((uint64_t)env_global + (uint64_t)episode * 7919u) % num_layouts);
+    uint32_t base = pool_word & 0xFFFFu, count = pool_word >> 16;
+    if (count == 0) { base = 0; count = num_layouts; }
+    return base + (uint32_t)(((uint64_t)env_global + (uint64_t)episode * 7919u) % count);
 }
 
 /* counter-based action stream shared by oracle, kernel and host: splitmix64 finaliser over (seed, env, agent, t) */
@@ -730,9 +732,9 @@ uint32_t czo_action(uint64_t seed, int64_t env_global, int agent, uint32_t step,
 int czo_reset_env(const czo_ctx *cx, int64_t env_local, uint32_t layout_id, uint32_t *rec, double *obs)
 {
     const czo_config *cfg = cx->cfg;
-    uint32_t recipes = rec[W_RECIPES], episode = rec[W_EPISODE];
+    uint32_t recipes = rec[W_RECIPES], episode = rec[W_EPISODE], pool = rec[W_POOL];
     memcpy(rec, cx->layouts[layout_id].init_record, sizeof(uint32_t) * (size_t)cfg->record_words);
-    rec[W_T] = 0; rec[W_LAYOUT] = layout_id; rec[W_STATUS] = 0; rec[W_EPISODE] = episode; rec[W_RECIPES] = recipes;
+    rec[W_T] = 0; rec[W_LAYOUT] = layout_id; rec[W_STATUS] = 0; rec[W_EPISODE] = episode; rec[W_RECIPES] = recipes; rec[W_POOL] = pool;
     static __thread World w;
     unpack(&w, cfg, rec);
     recompute_marks(cx, &w, rec);
@@ -753,7 +755,7 @@ int czo_step_env(const czo_ctx *cx, int64_t env_local, uint32_t *rec, const int3
         if (cfg->auto_reset) {
             uint32_t ep = rec[W_EPISODE] + 1;
             rec[W_EPISODE] = ep;
-            uint32_t lay = czo_next_layout(cx->env_id_base + env_local, ep, (uint32_t)cfg->num_layouts);
+            uint32_t lay = czo_next_layout(cx->env_id_base + env_local, ep, rec[W_POOL], (uint32_t)cfg->num_layouts);
             int e = czo_reset_env(cx, env_local, lay, rec, obs);
             for (int a = 0; a < A; ++a) { rewards[a] = 0.0; term[a] = 0; trunc[a] = 0; }
             return e;

@@ -56,3 +56,20 @@ class GoldenSet:
         self.meta = load_meta_file(self.cfg["meta_file"])
         self.episodes = [Episode(z, i, m) for i, m in enumerate(self.cfg["episodes"])]
         self.scheme = 3 if self.cfg["action_scheme"] == "scheme3" else 1
+
+
+def layout_from_episode(ep):
+    """Rebuild a cooking_zoo_amd Layout from the reference-captured initial state of a golden episode."""
+    from cooking_zoo_amd.cooking_world.layout import Layout
+    d = ep.dims
+    rec = ep.states[0]
+    cells = soa.record_cells(d, rec) & soa.CELL_TYPE_MASK
+    counts, xy = {}, []
+    for s in range(d.D):
+        x, y, c, f = soa.unpack_dyn0(rec[d.dyn0_word0 + s])
+        if f & soa.DYN_ALIVE:
+            counts[c] = counts.get(c, 0) + 1
+            xy.append((x, y))
+    dyn_classes = [(soa.DYNAMIC_CLASSES.index(n), counts[soa.DYNAMIC_CLASSES.index(n)]) for n in ep.class_order]
+    agents = [soa.unpack_agent(rec[soa.AGENT_WORD0 + a])[:2] for a in range(d.A)]
+    return Layout(d.W, d.H, cells, ep.static_lists(), dyn_classes, xy, agents)

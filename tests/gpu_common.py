@@ -1,0 +1,134 @@
+"""Helpers shared by the -m gpu tests: build a device handle straight from golden fixtures."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from cooking_zoo_amd import _native, soa
+from golden_io import RECIPE_NAMES, layout_from_episode, recipe_table
+from oracle_binding import Oracle
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Handle:
+    """Thin RAII wrapper over the raw C-ABI (tests call exactly what a foreign host would call)."""
+
+    def __init__(self, dims, n_envs, *, scheme, max_steps, end_all, num_recipes, reward_scheme=None, auto_reset=0,
+                 env_id_base=0):
+        self.L = _native.lib()
+        rs = {"recipe_reward": 20, "max_time_penalty": -5, "recipe_penalty": -40, "recipe_node_reward": 0}
+        rs.update(reward_scheme or {})
+        self.dims, self.n = dims, n_envs
+        cfg = _native.CzConfig(n_envs, dims.A, dims.W, dims.H, dims.D, dims.F, scheme, max_steps, int(end_all),
+                               num_recipes, auto_reset, 0, env_id_base, float(rs["recipe_reward"]),
+                               float(rs["max_time_penalty"]), float(rs["recipe_penalty"]),
+                               float(rs["recipe_node_reward"]))
+        self.h = C.c_void_p()
+        rc = self.L.cz_create(C.byref(cfg), C.byref(self.h))
+        if rc:
+            raise RuntimeError(self.L.cz_last_error(None).decode())
+        assert self.L.cz_record_words(self.h) == dims.RW
+        tab = recipe_table()
+        self.ck(self.L.cz_load_recipes(self.h, _ptr(tab), tab.shape[0]))
+
+    def ck(self, rc):
+        _native.check(self.h, rc)
+
+    def load_layouts(self, records, descs):
+        records = np.ascontiguousarray(records, dtype=np.uint32)
+        descs = np.ascontiguousarray(descs, dtype=np.uint32)
+        self.ck(self.L.cz_load_layouts(self.h, _ptr(records), _ptr(descs), records.shape[0]))
+
+    def reset(self, layout_ids, recipe_ids, pools=None, want_obs=True, begin=0):
+        ids = np.ascontiguousarray(layout_ids, dtype=np.int32)
+        rid = np.ascontiguousarray(recipe_ids, dtype=np.uint8)
+        pools = None if pools is None else np.ascontiguousarray(pools, dtype=np.uint32)
+        obs = np.empty((len(ids), self.dims.A, self.dims.F)) if want_obs else None
+        self.ck(self.L.cz_reset(self.h, begin, len(ids), _ptr(ids), _ptr(rid), _ptr(pools), _ptr(obs)))
+        return obs
+
+    def step(self, actions, want_obs=True):
+        A, F, n = self.dims.A, self.dims.F, self.n
+        acts = np.ascontiguousarray(actions, dtype=np.int32)
+        obs = np.empty((n, A, F)) if want_obs else None
+        rew = np.empty((n, A))
+        term = np.empty((n, A), dtype=np.uint8)
+        trunc = np.empty((n, A), dtype=np.uint8)
+        self.ck(self.L.cz_step(self.h, _ptr(acts), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc)))
+        return obs, rew, term, trunc
+
+    def get_state(self, begin=0, count=None):
+        count = self.n if count is None else count
+        recs = np.empty((count, self.dims.RW), dtype=np.uint32)
+        self.ck(self.L.cz_get_state(self.h, begin, count, _ptr(recs)))
+        return recs
+
+    def set_state(self, recs, begin=0):
+        recs = np.ascontiguousarray(recs, dtype=np.uint32)
+        self.ck(self.L.cz_set_state(self.h, begin, recs.shape[0], _ptr(recs)))
+
+    def observe(self, begin=0, count=None):
+        count = self.n if count is None else count
+        obs = np.empty((count, self.dims.A, self.dims.F))
+        self.ck(self.L.cz_observe(self.h, begin, count, _ptr(obs)))
+        return obs
+
+    def dev_alloc(self, nbytes):
+        p = self.L.cz_dev_alloc(self.h, nbytes)
+        assert p
+        return p
+
+    def d2h(self, ptr, shape, dtype):
+        out = np.empty(shape, dtype)
+        self.ck(self.L.cz_memcpy_d2h(self.h, _ptr(out), ptr, out.nbytes))
+        return out
+
+    def h2d(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self.ck(self.L.cz_memcpy_h2d(self.h, ptr, _ptr(arr), arr.nbytes))
+
+    def stats(self):
+        st = _native.CzStats()
+        self.ck(self.L.cz_get_stats(self.h, C.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if self.h:
+            self.L.cz_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def handle_for_set(gs, **kw):
+    """One env per golden episode of the set, layout i = episode i."""
+    eps = gs.episodes
+    dims = eps[0].dims
+    h = Handle(dims, len(eps), scheme=gs.scheme, max_steps=gs.cfg["max_steps"],
+               end_all=gs.cfg["end_condition_all_dishes"], num_recipes=len(gs.cfg["recipes"]),
+               reward_scheme=gs.cfg.get("reward_scheme"), **kw)
+    rid = [RECIPE_NAMES.index(r) for r in gs.cfg["recipes"]]
+    lays = [layout_from_episode(ep) for ep in eps]
+    h.load_layouts(np.stack([l.init_record(dims, i, rid) for i, l in enumerate(lays)]),
+                   np.stack([l.obs_descriptor(gs.meta, dims) for l in lays]))
+    rids = np.full((len(eps), 4), 0xFF, dtype=np.uint8)
+    rids[:, :len(rid)] = rid
+    return h, rids, lays
+
+
+def oracle_for_set(gs, lays, **kw):
+    eps = gs.episodes
+    dims = eps[0].dims
+    rid = [RECIPE_NAMES.index(r) for r in gs.cfg["recipes"]]
+    layouts = []
+    for i, l in enumerate(lays):
+        off, cells = l.static_table()
+        layouts.append((l.init_record(dims, i, rid), off, cells))
+    return Oracle(dims, gs.meta, recipe_table(), layouts, scheme=gs.scheme, max_steps=gs.cfg["max_steps"],
+                  end_condition_all=gs.cfg["end_condition_all_dishes"], num_recipes=len(gs.cfg["recipes"]),
+                  reward_scheme=gs.cfg.get("reward_scheme"), **kw)

@@ -45,7 +45,7 @@ def load_lib():
     lib.czo_action.restype = C.c_uint32
     lib.czo_action.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_uint32, C.c_uint32]
     lib.czo_next_layout.restype = C.c_uint32
-    lib.czo_next_layout.argtypes = [C.c_int64, C.c_uint32, C.c_uint32]
+    lib.czo_next_layout.argtypes = [C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32]
     return lib
 
 

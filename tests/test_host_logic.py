@@ -1,0 +1,134 @@
+"""CPU tests of the host side: layouts, observation descriptors, recipe tables, the C-ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cooking_zoo_amd import _native, soa
+from cooking_zoo_amd.cooking_book.recipe_drawer import RECIPES, DEFAULT_NUM_GOALS
+from cooking_zoo_amd.cooking_world.layout import feature_length
+from cooking_zoo_amd.cooking_world.engine.load_level import load_meta_file
+from golden_io import GoldenSet, golden_sets, layout_from_episode, recipe_table, RECIPE_NAMES
+from oracle_binding import Oracle
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_feature_length_example_meta():
+    assert feature_length(load_meta_file("example")) == 278
+    assert feature_length(load_meta_file("large_16x16")) == 840       # SURVEY 8d cfg 5
+
+
+def test_recipe_book_matches_survey_b2():
+    assert DEFAULT_NUM_GOALS == 26
+    ids = {n: [(x.name, x.id_num) for x in RECIPES[n]().node_list] for n in RECIPES}
+    assert ids["TomatoLettuceSalad"] == [("Deliversquare", 18), ("Plate", 11), ("Tomato", 2), ("Lettuce", 0)]
+    assert ids["MashedCarrotBanana"] == [("Deliversquare", 21), ("Plate", 14), ("Carrot", 9), ("Banana", 7)]
+    assert ids["no_recipe"] == [("Deliversquare", 25), ("Floor", 24)]
+    assert list(RECIPES) == ["TomatoSalad", "TomatoLettuceSalad", "CarrotBanana", "MashedCarrotBanana", "CucumberOnion",
+                             "AppleWatermelon", "TomatoLettuceOnionSalad", "no_recipe"]
+    r = RECIPES["TomatoLettuceSalad"]()
+    assert r.goals_completed(26).sum() == 4 and not r.completed()
+    r.set_marks(0b1111)
+    assert r.goals_completed(26).sum() == 0 and r.completed()
+
+
+@pytest.mark.parametrize("name", golden_sets())
+def test_layout_record_and_descriptor_match_reference(name):
+    """Layout.init_record reproduces the reference's freshly reset world, and the obs descriptor table,
+    evaluated on the host, reproduces the reference's observation at every 7th golden step."""
+    gs = GoldenSet(name)
+    for ep in gs.episodes:
+        lay = layout_from_episode(ep)
+        rid = [RECIPE_NAMES.index(r) for r in gs.cfg["recipes"]]
+        rec = lay.init_record(ep.dims, 0, rid)
+        ref = ep.states[0].copy()
+        rec[soa.W_MARKS] = ref[soa.W_MARKS]
+        assert np.array_equal(rec, ref), name
+        desc = lay.obs_descriptor(gs.meta, ep.dims)
+        for t in range(0, len(ep.states), 7):
+            got = eval_descriptor(desc, ep.dims, ep.states[t])
+            assert np.array_equal(bits(got), bits(ep.obs[t])), (name, t)
+
+
+def eval_descriptor(desc, d, rec):
+    """numpy restatement of the kernel's descriptor walk (host-side check of the table builder)."""
+    out = np.zeros((d.A, d.F))
+    cells = soa.record_cells(d, rec)
+    ag = [soa.unpack_agent(rec[soa.AGENT_WORD0 + a]) for a in range(d.A)]
+    for f, w in enumerate(desc):
+        op, ref = int(w) & 0xFF, int(w) >> 8
+        for a in range(d.A):
+            ax, ay = ag[a][0], ag[a][1]
+            v = 0.0
+            if op == soa.OP_ONE:
+                v = 1.0
+            elif op == soa.OP_CONST_X:
+                v = (ref - ax) / d.W
+            elif op == soa.OP_CONST_Y:
+                v = (ref - ay) / d.H
+            elif op == soa.OP_CELL_ACTIVE:
+                v = float(bool(cells[ref] & soa.CELL_ACTIVE))
+            elif op == soa.OP_CELL_WALK:
+                v = float(bool(cells[ref] & soa.CELL_WALK))
+            elif soa.OP_DYN_X <= op <= soa.OP_DYN_ONE:
+                x, y, c, fl = soa.unpack_dyn0(rec[d.dyn0_word0 + ref])
+                if fl & soa.DYN_ALIVE:
+                    done = bool(fl & (soa.DYN_CHOPPED | soa.DYN_MASHED))
+                    v = {soa.OP_DYN_X: (x - ax) / d.W, soa.OP_DYN_Y: (y - ay) / d.H, soa.OP_DYN_NOTDONE: float(not done),
+                         soa.OP_DYN_DONE: float(done), soa.OP_DYN_CHOPPED: float(bool(fl & soa.DYN_CHOPPED)),
+                         soa.OP_DYN_MASHED: float(bool(fl & soa.DYN_MASHED)), soa.OP_DYN_ONE: 1.0}[op]
+            elif op >= soa.OP_AG_X:
+                gx, gy, go, _ = ag[ref]
+                if op == soa.OP_AG_X:
+                    v = gx / d.W if ref == a else (gx - ax) / d.W
+                elif op == soa.OP_AG_Y:
+                    v = gy / d.H if ref == a else (gy - ay) / d.H
+                elif op == soa.OP_AG_ONE:
+                    v = 1.0
+                else:
+                    v = float(go == op - soa.OP_AG_O1 + 1)
+            out[a, f] = v
+    return out
+
+
+def test_c_abi_exports_every_declared_symbol(repo_root):
+    """The shared library loads (no GPU needed) and exports every function include/cookingzoo.h declares."""
+    hdr = open(os.path.join(repo_root, "include", "cookingzoo.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cz_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in cookingzoo.h but not exported"
+    assert declared == {n for n, _, _ in _native.SYMBOLS}, "ctypes binding and header disagree"
+    assert _native.lib().cz_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    L = _native.lib()
+    assert ctypes.sizeof(_native.CzConfig) == L.cz_sizeof_config() == 12 * 4 + 8 + 4 * 8
+    assert ctypes.sizeof(_native.CzStats) == L.cz_sizeof_stats() == 9 * 8 + 4 * 8
+
+
+def test_action_stream_matches_oracle():
+    """The counter-based action stream is the same function in the library and in the oracle."""
+    from oracle_binding import load_lib
+    o, L = load_lib(), _native.lib()
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        seed, env, ag, step = int(rng.integers(1 << 62)), int(rng.integers(1 << 40)), int(rng.integers(4)), int(rng.integers(1 << 31))
+        for n in (5, 8):
+            a, b = o.czo_action(seed, env, ag, step, n), L.cz_action(seed, env, ag, step, n)
+            assert a == b and 0 <= a < n
+    hist = np.bincount([L.cz_action(7, e, 0, t, 5) for e in range(200) for t in range(50)], minlength=5)
+    assert hist.min() > 1700 and hist.max() < 2300
+    o.czo_next_layout.argtypes = [ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    for e in range(50):
+        for ep in range(5):
+            for pool in (0, 3 | (5 << 16)):
+                assert o.czo_next_layout(e, ep, pool, 11) == L.cz_next_layout(e, ep, pool, 11)
