@@ -132,3 +132,62 @@ class Oracle:
                                    C.c_uint32(step0), self._p(obs), self._p(rew), self._p(term), self._p(trunc),
                                    self._p(acts))
         return err, obs, rew, term, trunc, acts
+
+
+class VecOracle:
+    """Oracle twin of a cooking_zoo_amd CookingVecEnv configuration (same layout pool, recipes, rewards):
+    the checker for smoke()/bench parity and the `cpu_baseline` leg of bench.py.  Built only from host-side
+    tables (layouts, meta, recipe table) -- it never touches the GPU library."""
+
+    def __init__(self, *, layouts, meta, recipe_table, recipe_ids, dims, scheme, max_steps, end_condition_all,
+                 num_recipes, reward_scheme, pool_slices, env_level, num_envs, env_id_base=0, auto_reset=1):
+        lay = []
+        for i, l in enumerate(layouts):
+            off, cells = l.static_table()
+            lay.append((l.init_record(dims, i), off, cells))
+        self.oracle = Oracle(dims, meta, recipe_table, lay, scheme=scheme, max_steps=max_steps,
+                             end_condition_all=end_condition_all, num_recipes=num_recipes, auto_reset=auto_reset,
+                             reward_scheme=reward_scheme, env_id_base=env_id_base)
+        self.dims, self.num_envs, self.env_id_base = dims, num_envs, env_id_base
+        self.records = np.zeros((num_envs, dims.RW), dtype=np.uint32)
+        self.recipe_ids = np.asarray(recipe_ids, dtype=np.uint8)
+        self.pool_slices, self.env_level = pool_slices, env_level
+        self.n_layouts = len(layouts)
+
+    @classmethod
+    def from_vec_env(cls, env, num_envs=None, env_id_base=None, auto_reset=1):
+        n = env.num_envs if num_envs is None else num_envs
+        return cls(layouts=env.layouts, meta=env.meta, recipe_table=env.recipe_table, recipe_ids=env.recipe_ids[:n],
+                   dims=env.dims, scheme=env.scheme_class.CODE, max_steps=env.max_steps,
+                   end_condition_all=env.end_condition_all_dishes, num_recipes=env.num_recipes,
+                   reward_scheme=env.reward_scheme, pool_slices=env.pool_slices, env_level=env.env_level[:n],
+                   num_envs=n, env_id_base=env.env_id_base if env_id_base is None else env_id_base,
+                   auto_reset=auto_reset)
+
+    def reset(self):
+        lib = self.oracle.lib
+        obs = np.empty((self.num_envs, self.dims.A, self.dims.F))
+        for e in range(self.num_envs):
+            base, count = self.pool_slices[self.env_level[e]]
+            pool = base | (count << 16)
+            lay = lib.czo_next_layout(self.env_id_base + e, 0, pool, self.n_layouts)
+            rec = self.records[e]
+            rec[:] = 0
+            rid = self.recipe_ids[e]
+            rec[soa.W_RECIPES] = int(rid[0]) | (int(rid[1]) << 8) | (int(rid[2]) << 16) | (int(rid[3]) << 24)
+            rec[soa.W_POOL] = pool
+            # czo_reset_env keys nothing on env index; env-local offset only matters for auto-reset draws
+            err = lib.czo_reset_env(C.byref(self.oracle.ctx), C.c_int64(e), C.c_uint32(lay),
+                                    rec.ctypes.data_as(C.c_void_p), obs[e].ctypes.data_as(C.c_void_p))
+            assert err == 0
+        return obs
+
+    def step(self, actions, want_obs=True):
+        err, obs, rew, term, trunc = self.oracle.step_batch(self.records, actions, want_obs)
+        assert err == 0, err
+        return obs, rew, term, trunc
+
+    def rollout(self, T, seed, step0=0, want_obs=True):
+        err, obs, rew, term, trunc, _ = self.oracle.rollout(self.records, T, seed, step0, want_obs)
+        assert err == 0, err
+        return obs, rew, term, trunc
