@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs", type=int, default=4096, help="env instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-obs", action="store_true", help="ablation only: skip the observation encode (INVALID as a result)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,7 +124,7 @@ def main():
 
     def run_steps(k, first):
         for t in range(first, first + k):
-            rc = L.cz_step_device(h, d_actions.ptr + (t % chunk) * step_bytes, d_obs.ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr)
+            rc = L.cz_step_device(h, d_actions.ptr + (t % chunk) * step_bytes, None if args.no_obs else d_obs.ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr)
             if rc:
                 _native.check(h, rc)
 

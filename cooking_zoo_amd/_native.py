@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcookingzoo_hip.so")
+LIB_PATH = os.environ.get("CZ_LIB", os.path.join(_HERE, "csrc", "libcookingzoo_hip.so"))   # CZ_LIB: diagnostic builds
 
 
 class CzConfig(C.Structure):
@@ -43,6 +43,7 @@ SYMBOLS = [
     ("cz_abi_version", _I32, []),
     ("cz_sizeof_config", _I32, []),
     ("cz_sizeof_stats", _I32, []),
+    ("cz_debug_set_stamps", C.c_int, [_VP, _VP]),
     ("cz_sync", C.c_int, [_VP]),
     ("cz_load_recipes", C.c_int, [_VP, _VP, _I32]),
     ("cz_load_layouts", C.c_int, [_VP, _VP, _VP, _I32]),

@@ -71,10 +71,11 @@ class Layout:
 
     # ------------------------------------------------------------------ observation descriptor
     def obs_descriptor(self, meta: dict, dims: soa.Dims) -> np.ndarray:
-        """uint32[F]: one (op | ref<<8) per feature, in the order cooking_env.py:352-373 emits them:
-        meta-file class order, list order inside a class, zero padding up to the meta count."""
+        """uint32[F]: one descriptor word (soa.desc_word) per feature, in the order cooking_env.py:352-373 emits
+        them: meta-file class order, list order inside a class, zero padding up to the meta count."""
         d = []
-        W = self.width
+        dw = soa.desc_word
+        zero = dw(soa.IMG_ZERO)
         for name, num in meta.items():
             flen = soa.FEATURE_LEN[name]
             emitted = 0
@@ -82,13 +83,11 @@ class Layout:
                 for c in self.static_lists.get(name, []):
                     if flen == 0:
                         continue
-                    x, y = c % W, c // W
-                    d += [soa.OP_CONST_X | (x << 8), soa.OP_CONST_Y | (y << 8)]
-                    if name == "Switch":
-                        d.append(soa.OP_CELL_ACTIVE | (c << 8))
-                    if name == "Block":
-                        d.append(soa.OP_CELL_WALK | (c << 8))
-                    d.append(soa.OP_ONE)
+                    i = soa.IMG_CELL0 + 4 * c
+                    d += [dw(i, soa.AX_X), dw(i + 1, soa.AX_Y)]
+                    if name in ("Switch", "Block"):
+                        d.append(dw(i + 2))                    # switch_active / int(walkable)
+                    d.append(dw(i + 3))
                     emitted += 1
                 if flen and emitted > num:
                     raise ValueError(f"level has {emitted} {name} objects, meta file allows {num}")
@@ -97,25 +96,26 @@ class Layout:
                 base, cap = self.slot_base.get(cls, 0), self.slot_cap.get(cls, 0)
                 # slots beyond the meta count cannot be encoded (the reference would emit an over-long vector)
                 for k in range(min(cap, num)):
-                    s = base + k
-                    d += [soa.OP_DYN_X | (s << 8), soa.OP_DYN_Y | (s << 8)]
+                    i = soa.IMG_OBJ0 + 6 * (base + k)
+                    d += [dw(i, soa.AX_X), dw(i + 1, soa.AX_Y)]
                     if cls != soa.PLATE:
-                        d.append(soa.OP_DYN_NOTDONE | (s << 8))
+                        d.append(dw(i + 2))                                    # int(not done())
                         if cls in soa.BLENDER_FOOD:
-                            d += [soa.OP_DYN_CHOPPED | (s << 8), soa.OP_DYN_MASHED | (s << 8)]
+                            d += [dw(i + 3), dw(i + 4)]                        # chopped, mashed
                         else:
-                            d.append(soa.OP_DYN_DONE | (s << 8))
-                    d.append(soa.OP_DYN_ONE | (s << 8))
+                            d.append(dw(i + 3))                                # int(done()) == chopped
+                    d.append(dw(i + 5))
                     emitted += 1
             elif name == "Agent":
                 for a in range(min(dims.A, num)):
-                    d += [soa.OP_AG_X | (a << 8), soa.OP_AG_Y | (a << 8), soa.OP_AG_O1 | (a << 8),
-                          soa.OP_AG_O2 | (a << 8), soa.OP_AG_O3 | (a << 8), soa.OP_AG_O4 | (a << 8),
-                          soa.OP_AG_ONE | (a << 8)]
+                    i = soa.IMG_AG0 + 8 * a
+                    d += [dw(i, soa.ax_self(a, 0)), dw(i + 1, soa.ax_self(a, 1))]
+                    d += [dw(i + 2 + o) for o in range(4)]
+                    d.append(dw(i + 6))
                     emitted += 1
             else:
                 raise KeyError(name)
-            d += [soa.OP_ZERO] * ((num - emitted) * flen)
+            d += [zero] * ((num - emitted) * flen)
         out = np.asarray(d, dtype=np.uint32)
         if out.size != dims.F:
             raise ValueError(f"descriptor length {out.size} != feature length {dims.F}")

@@ -1,357 +1,35 @@
-// cz_api.hip -- kernels + C-ABI (include/cookingzoo.h) of the MI355X-native CookingZoo step path.
-// gfx950 only.  One wavefront (64 lanes, one 64-thread workgroup) per env instance; see cz_device.h.
+// cz_api.hip -- C-ABI (include/cookingzoo.h) of the MI355X-native CookingZoo step path: handle, tables, launches,
+// statistics, RCCL.  The kernels live in cz_kernels.h / cz_device.h (one wavefront per env instance) and are
+// instantiated in cz_inst_small.hip / cz_inst_large.hip.  gfx950 only.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
 #include <vector>
 
 #include "../../include/cookingzoo.h"
-#include "cz_device.h"
+#include "cz_kernels.h"
 
 using namespace cz;
 
-// ======================================================================================================
-// device: load / store / reset / observe / one full step
-// ======================================================================================================
-
-template <int OPL, int CPL>
-__device__ __forceinline__ void load_env(const Params &P, Env<OPL, CPL> &e, const Ctx &cx, const uint32_t *__restrict__ rec) {
-    uint32_t h = (cx.lane < CELL_WORD0) ? rec[cx.lane] : 0u;
-    e.t = rdl(h, W_T); e.marks = rdl(h, W_MARKS); e.layout = rdl(h, W_LAYOUT); e.status = rdl(h, W_STATUS);
-    e.episode = rdl(h, W_EPISODE); e.recipes = rdl(h, W_RECIPES); e.pool = rdl(h, W_POOL);
-#pragma unroll
-    for (int a = 0; a < MAX_AGENTS; ++a) {
-        uint32_t w = rdl(h, AGENT_WORD0 + a);
-        e.ax[a] = (int)(w & 0xFF); e.ay[a] = (int)((w >> 8) & 0xFF); e.ao[a] = (int)((w >> 16) & 0xFF);
-        e.ah[a] = (int)((w >> 24) & 0xFF) - 1;
-    }
-    const uint8_t *cb = reinterpret_cast<const uint8_t *>(rec + CELL_WORD0);
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        int c = cx.lane + 64 * k;
-        e.cell[k] = (c < cx.W * cx.H) ? (uint32_t)cb[c] : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < OPL; ++k) {
-        int s = cx.lane + 64 * k;
-        e.d0[k] = (s < cx.D) ? rec[P.dyn0_off + s] : 0u;
-        e.d1[k] = (s < cx.D) ? rec[P.dyn1_off + s] : 0u;
-    }
-}
-
-template <int OPL, int CPL>
-__device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL> &e, const Ctx &cx, uint32_t *__restrict__ rec) {
-    uint32_t h = 0;
-    const int l = cx.lane;
-    if (l == W_T) h = e.t;
-    if (l == W_MARKS) h = e.marks;
-    if (l == W_LAYOUT) h = e.layout;
-    if (l == W_STATUS) h = e.status;
-    if (l == W_EPISODE) h = e.episode;
-    if (l == W_RECIPES) h = e.recipes;
-    if (l == W_POOL) h = e.pool;
-#pragma unroll
-    for (int a = 0; a < MAX_AGENTS; ++a)
-        if (l == AGENT_WORD0 + a)
-            h = (a < cx.A) ? ((uint32_t)e.ax[a] | ((uint32_t)e.ay[a] << 8) | ((uint32_t)e.ao[a] << 16) |
-                              ((uint32_t)((e.ah[a] + 1) & 0xFF) << 24))
-                           : 0u;
-    if (l < CELL_WORD0) rec[l] = h;
-    uint8_t *cb = reinterpret_cast<uint8_t *>(rec + CELL_WORD0);
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        int c = l + 64 * k;
-        if (c < cx.W * cx.H) cb[c] = (uint8_t)e.cell[k];
-    }
-#pragma unroll
-    for (int k = 0; k < OPL; ++k) {
-        int s = l + 64 * k;
-        if (s < cx.D) {
-            rec[P.dyn0_off + s] = e.d0[k];
-            rec[P.dyn1_off + s] = e.d1[k];
-        }
-    }
-}
-
-template <int OPL, int CPL>
-__device__ __forceinline__ uint32_t all_marks(const Params &P, const Env<OPL, CPL> &e, const Ctx &cx) {
-    uint32_t marks = 0;
-#pragma unroll
-    for (int r = 0; r < MAX_AGENTS; ++r) {
-        if (r >= P.R) continue;
-        uint32_t id = (e.recipes >> (8 * r)) & 0xFF;
-        marks |= Ops<OPL, CPL>::recipe_marks(e, cx, P.recipes + (size_t)id * (1 + MAX_NODES)) << (8 * r);
-    }
-    return marks;
-}
-
-// LDS image of one env (per wave): what the feature encode gathers from
-template <int OPL, int CPL>
-struct Lds {
-    uint32_t d0[OPL * 64];
-    uint32_t cell[CPL * 64];
-    double lutx[64], luty[64];     // (i - (W-1)) / W and (i - (H-1)) / H, i in [0, 2W-2]: exact IEEE quotients
-};
-
-// cooking_env.py:352-373 get_feature_vector for every agent of the env, through the layout's descriptor table
-template <int OPL, int CPL>
-__device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL> &e, const Ctx &cx, Lds<OPL, CPL> &s,
-                                        double *__restrict__ out /* [A][F] of this env */) {
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < OPL; ++k) s.d0[cx.lane + 64 * k] = e.d0[k];
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) s.cell[cx.lane + 64 * k] = e.cell[k];
-    __syncthreads();
-    const uint32_t *__restrict__ desc = P.lay_desc + (size_t)e.layout * P.F;
-    for (int f = cx.lane; f < P.F; f += 64) {
-        const uint32_t dsc = desc[f];
-        const uint32_t op = dsc & 0xFF, ref = dsc >> 8;
-        int kind = 0;            // 0: constant v, 1: x-like coordinate, 2: y-like coordinate
-        int coord = 0, self = -1;
-        double v = 0.0;
-        if (op == OP_ONE) v = 1.0;
-        else if (op == OP_CONST_X) { kind = 1; coord = (int)ref; }
-        else if (op == OP_CONST_Y) { kind = 2; coord = (int)ref; }
-        else if (op == OP_CELL_ACTIVE) v = (s.cell[ref] & CELL_ACTIVE) ? 1.0 : 0.0;
-        else if (op == OP_CELL_WALK) v = (s.cell[ref] & CELL_WALK) ? 1.0 : 0.0;
-        else if (op >= OP_DYN_X && op <= OP_DYN_ONE) {
-            const uint32_t w = s.d0[ref];
-            if (w & D_ALIVE) {
-                if (op == OP_DYN_X) { kind = 1; coord = (int)(w & 0xFF); }
-                else if (op == OP_DYN_Y) { kind = 2; coord = (int)((w >> 8) & 0xFF); }
-                else if (op == OP_DYN_NOTDONE) v = (w & D_DONE) ? 0.0 : 1.0;
-                else if (op == OP_DYN_DONE) v = (w & D_DONE) ? 1.0 : 0.0;
-                else if (op == OP_DYN_CHOPPED) v = (w & D_CHOPPED) ? 1.0 : 0.0;
-                else if (op == OP_DYN_MASHED) v = (w & D_MASHED) ? 1.0 : 0.0;
-                else v = 1.0;
-            }
-        } else if (op >= OP_AG_X) {
-            int gx = 0, gy = 0, go = 0;
-#pragma unroll
-            for (int a = 0; a < MAX_AGENTS; ++a)
-                if ((int)ref == a) { gx = e.ax[a]; gy = e.ay[a]; go = e.ao[a]; }
-            if (op == OP_AG_X) { kind = 1; coord = gx; self = (int)ref; }
-            else if (op == OP_AG_Y) { kind = 2; coord = gy; self = (int)ref; }
-            else if (op == OP_AG_ONE) v = 1.0;
-            else v = (go == (int)(op - OP_AG_O1) + 1) ? 1.0 : 0.0;
-        }
-#pragma unroll
-        for (int a = 0; a < MAX_AGENTS; ++a) {
-            if (a >= cx.A) continue;
-            double val = v;
-            if (kind == 1) val = s.lutx[coord - (self == a ? 0 : e.ax[a]) + (cx.W - 1)];
-            else if (kind == 2) val = s.luty[coord - (self == a ? 0 : e.ay[a]) + (cx.H - 1)];
-            out[(size_t)a * P.F + f] = val;
-        }
-    }
-}
-
-struct StepOut {
-    double rew[MAX_AGENTS];
-    uint32_t term, trunc, was_reset;
-};
-
-// One accumulated_step (cooking_env.py:243-269) of one env held in registers.
-template <int OPL, int CPL>
-__device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL> &e, const Ctx &cx, const int (&acts)[MAX_AGENTS],
-                                         int64_t env_global, StepOut &o) {
-    using O = Ops<OPL, CPL>;
-#pragma unroll
-    for (int a = 0; a < MAX_AGENTS; ++a) o.rew[a] = 0.0;
-    o.term = 0; o.trunc = 0; o.was_reset = 0;
-    if (e.status & ST_DONE) {
-        if (P.auto_reset) {
-            // next-step autoreset: reset() of cooking_env.py:178-210 from the layout pool
-            e.episode += 1;
-            uint32_t lay = next_layout(env_global, e.episode, e.pool, (uint32_t)P.L);
-            uint32_t recipes = e.recipes, episode = e.episode, pool = e.pool;
-            load_env(P, e, cx, P.lay_init + (size_t)lay * P.RW);
-            e.t = 0; e.layout = lay; e.status = 0; e.episode = episode; e.recipes = recipes; e.pool = pool;
-            e.marks = all_marks(P, e, cx);
-            o.was_reset = 1;
-        } else {
-            o.term = (e.status & ST_TERM) ? 1u : 0u;
-            o.trunc = (e.status & ST_TRUNC) ? 1u : 0u;
-        }
-        return;
-    }
-    e.t += 1;                                                        // cooking_env.py:244
-    uint32_t pressed = 0;
-    O::perform_agent_actions(e, cx, acts, P.scheme, pressed);       // cooking_world.py:104-108
-    O::progress_and_link(e, cx, pressed);                           // :109-110 (handle_agent_spawn: neutral at rate 0)
-    // compute_rewards cooking_env.py:290-315
-    const bool truncated = (int)e.t >= P.max_steps;                 // compute_truncated :333-350
-    const uint32_t before = e.marks;
-    uint32_t after = 0;
-    int n_completed = 0;
-#pragma unroll
-    for (int r = 0; r < MAX_AGENTS; ++r) {
-        if (r >= P.R) continue;
-        const uint32_t id = (e.recipes >> (8 * r)) & 0xFF;
-        const uint32_t *rp = P.recipes + (size_t)id * (1 + MAX_NODES);
-        const uint32_t ma = O::recipe_marks(e, cx, rp);
-        const uint32_t mb = (before >> (8 * r)) & 0xFF;
-        after |= ma << (8 * r);
-        // goals_completed sums (recipe.py:36-40): open goal slots before / after
-        uint32_t countmask = 0;
-        const int n = (int)rfl(rp[0]);
-#pragma unroll
-        for (int j = 0; j < MAX_NODES; ++j)
-            if (j < n && ((rfl(rp[1 + j]) >> 24) & 1)) countmask |= 1u << j;
-        const int goals_before = __popc(~mb & countmask), goals_after = __popc(~ma & countmask);
-        const bool completed = ma & 1, completion_before = mb & 1;
-        const bool malus = !completed && completion_before, bonus = completed && !completion_before;
-        double x = 0.0;
-        x += (double)(goals_before - goals_after) * P.node_reward;
-        x += (bonus ? 1.0 : 0.0) * P.recipe_reward;
-        x += (malus ? 1.0 : 0.0) * P.recipe_penalty;
-        x += P.time_penalty_step;
-        if (r < cx.A) o.rew[r] = x;
-        n_completed += completed ? 1 : 0;
-    }
-    e.marks = after;
-    const bool done = P.end_all ? (n_completed == P.R) : (n_completed > 0);
-    o.term = done ? 1u : 0u;
-    o.trunc = truncated ? 1u : 0u;
-    if (done || truncated) e.status |= ST_DONE | (done ? ST_TERM : 0u) | (truncated ? ST_TRUNC : 0u);
-}
-
-template <int OPL, int CPL>
-__global__ __launch_bounds__(64) void k_step(Params P) {
-    __shared__ Lds<OPL, CPL> lds;
-    const int env = blockIdx.x;
-    Ctx cx{P.A, P.W, P.H, P.D, (int)threadIdx.x};
-    if (cx.lane < 2 * P.W - 1) lds.lutx[cx.lane] = (double)(cx.lane - (P.W - 1)) / (double)P.W;
-    if (cx.lane < 2 * P.H - 1) lds.luty[cx.lane] = (double)(cx.lane - (P.H - 1)) / (double)P.H;
-    Env<OPL, CPL> e;
-    uint32_t *rec = P.state + (size_t)env * P.RW;
-    load_env(P, e, cx, rec);
-    const int64_t env_global = P.env_id_base + env;
-
-    // statistics registers (lane-replicated uniform values)
-    uint32_t *su = P.stat_u + (size_t)env * SU_WORDS;
-    double *sf = P.stat_f + (size_t)env * SF_WORDS;
-    uint32_t s_steps = 0, s_episodes = 0, s_lensum = 0, s_trunc = 0, s_term = 0;
-    uint32_t s_completed[MAX_AGENTS] = {0, 0, 0, 0};
-    double s_cur[MAX_AGENTS], s_sum[MAX_AGENTS] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int a = 0; a < MAX_AGENTS; ++a) s_cur[a] = (a < P.A) ? sf[SF_CUR0 + a] : 0.0;
-
-    for (int t = 0; t < P.T; ++t) {
-        int acts[MAX_AGENTS] = {0, 0, 0, 0};
-        if (P.actions) {
-            int v = (cx.lane < P.A) ? P.actions[(size_t)env * P.A + cx.lane] : 0;
-#pragma unroll
-            for (int a = 0; a < MAX_AGENTS; ++a) acts[a] = (int)rdl((uint32_t)v, a);
-        } else {
-            const uint32_t nact = P.scheme == 3 ? 5u : 8u;
-#pragma unroll
-            for (int a = 0; a < MAX_AGENTS; ++a)
-                acts[a] = (a < P.A) ? (int)action_hash(P.seed, env_global, a, P.step0 + (uint32_t)t, nact) : 0;
-        }
-        const bool was_done = (e.status & ST_DONE) != 0;
-        StepOut o;
-        step_env(P, e, cx, acts, env_global, o);
-        // ---- statistics
-        if (!was_done) {
-            s_steps += 1;
-#pragma unroll
-            for (int a = 0; a < MAX_AGENTS; ++a) s_cur[a] += o.rew[a];
-            if (e.status & ST_DONE) {
-                s_episodes += 1;
-                s_lensum += e.t;
-                s_trunc += o.trunc;
-                s_term += o.term;
-#pragma unroll
-                for (int a = 0; a < MAX_AGENTS; ++a) {
-                    if (a >= P.A) continue;
-                    s_sum[a] += s_cur[a];
-                    s_cur[a] = 0.0;
-                    s_completed[a] += (e.marks >> (8 * a)) & 1u;
-                }
-            }
-        }
-        // ---- outputs of this step
-        const size_t row = (size_t)t * P.N + env;
-        if (P.rewards && cx.lane < P.A) {
-            double r = 0.0;
-#pragma unroll
-            for (int a = 0; a < MAX_AGENTS; ++a)
-                if (cx.lane == a) r = o.rew[a];
-            P.rewards[row * P.A + cx.lane] = r;
-        }
-        if (P.term && cx.lane < P.A) P.term[row * P.A + cx.lane] = (uint8_t)o.term;
-        if (P.trunc && cx.lane < P.A) P.trunc[row * P.A + cx.lane] = (uint8_t)o.trunc;
-        if (P.obs) observe(P, e, cx, lds, P.obs + row * (size_t)P.A * P.F);
-    }
-    store_env(P, e, cx, rec);
-    if (cx.lane == 0) {
-        su[SU_STEPS] += s_steps; su[SU_EPISODES] += s_episodes; su[SU_LENSUM] += s_lensum;
-        su[SU_TRUNC] += s_trunc; su[SU_TERM] += s_term;
-    }
-    if (cx.lane < P.A) {
-        uint32_t c = 0;
-        double cur = 0.0, sum = 0.0;
-#pragma unroll
-        for (int a = 0; a < MAX_AGENTS; ++a)
-            if (cx.lane == a) { c = s_completed[a]; cur = s_cur[a]; sum = s_sum[a]; }
-        su[SU_COMPLETED0 + cx.lane] += c;
-        sf[SF_CUR0 + cx.lane] = cur;
-        sf[SF_SUM0 + cx.lane] += sum;
-    }
-}
-
-// reset(): cooking_env.py:178-210 for envs [env_begin, env_begin + count)
-template <int OPL, int CPL>
-__global__ __launch_bounds__(64) void k_reset(Params P, int64_t env_begin, const int32_t *__restrict__ layout_ids,
-                                              const uint32_t *__restrict__ recipe_words, const uint32_t *__restrict__ pool_words, double *obs_out) {
-    __shared__ Lds<OPL, CPL> lds;
-    const int i = blockIdx.x;
-    const int64_t env = env_begin + i;
-    Ctx cx{P.A, P.W, P.H, P.D, (int)threadIdx.x};
-    if (cx.lane < 2 * P.W - 1) lds.lutx[cx.lane] = (double)(cx.lane - (P.W - 1)) / (double)P.W;
-    if (cx.lane < 2 * P.H - 1) lds.luty[cx.lane] = (double)(cx.lane - (P.H - 1)) / (double)P.H;
-    Env<OPL, CPL> e;
-    uint32_t *rec = P.state + (size_t)env * P.RW;
-    const uint32_t lay = rfl((uint32_t)layout_ids[i]);
-    const uint32_t old_episode = rfl(rec[W_EPISODE]);
-    load_env(P, e, cx, P.lay_init + (size_t)lay * P.RW);
-    e.t = 0; e.layout = lay; e.status = 0; e.episode = old_episode; e.recipes = rfl(recipe_words[i]);
-    e.pool = rfl(pool_words[i]);
-    e.marks = all_marks(P, e, cx);
-    store_env(P, e, cx, rec);
-    if (cx.lane < P.A) P.stat_f[(size_t)env * SF_WORDS + SF_CUR0 + cx.lane] = 0.0;
-    if (obs_out) observe(P, e, cx, lds, obs_out + (size_t)i * P.A * P.F);
-}
-
-// observe() only (used after cz_set_state by the host API)
-template <int OPL, int CPL>
-__global__ __launch_bounds__(64) void k_observe(Params P, int64_t env_begin, double *obs_out) {
-    __shared__ Lds<OPL, CPL> lds;
-    const int i = blockIdx.x;
-    Ctx cx{P.A, P.W, P.H, P.D, (int)threadIdx.x};
-    if (cx.lane < 2 * P.W - 1) lds.lutx[cx.lane] = (double)(cx.lane - (P.W - 1)) / (double)P.W;
-    if (cx.lane < 2 * P.H - 1) lds.luty[cx.lane] = (double)(cx.lane - (P.H - 1)) / (double)P.H;
-    Env<OPL, CPL> e;
-    load_env(P, e, cx, P.state + (size_t)(env_begin + i) * P.RW);
-    observe(P, e, cx, lds, obs_out + (size_t)i * P.A * P.F);
-}
-
-// deterministic reduction of the per-env statistics into one cz_stats (fixed thread->env mapping, fixed tree)
-__global__ __launch_bounds__(256) void k_stats_reduce(const uint32_t *__restrict__ su, const double *__restrict__ sf, int N,
-                                                      cz_stats *out) {
+// deterministic reduction of the per-env statistics into one cz_stats (fixed thread->env mapping, fixed tree).
+// env_steps = finished-episode lengths + steps of the episode in flight + the signed correction word SU_STEPS
+// (steps of episodes aborted by cz_reset, minus what was in flight at cz_reset_stats).
+__global__ __launch_bounds__(256) void k_stats_reduce(const uint32_t *__restrict__ su, const double *__restrict__ sf,
+                                                      const uint32_t *__restrict__ state, int RW, int N, cz_stats *out) {
     __shared__ unsigned long long su64[256][9];
     __shared__ double sd[256][4];
     unsigned long long acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double ret[4] = {0.0, 0.0, 0.0, 0.0};
     for (int e = threadIdx.x; e < N; e += 256) {
         const uint32_t *p = su + (size_t)e * SU_WORDS;
-        acc[0] += p[SU_STEPS]; acc[1] += p[SU_EPISODES]; acc[2] += p[SU_LENSUM]; acc[3] += p[SU_TRUNC]; acc[4] += p[SU_TERM];
+        const uint32_t *rec = state + (size_t)e * RW;
+        long long steps = (long long)(int)p[SU_STEPS] + (long long)p[SU_LENSUM] + ((rec[W_STATUS] & ST_DONE) ? 0 : (long long)rec[W_T]);
+        acc[0] += (unsigned long long)steps; acc[1] += p[SU_EPISODES]; acc[2] += p[SU_LENSUM]; acc[3] += p[SU_TRUNC]; acc[4] += p[SU_TERM];
         for (int a = 0; a < 4; ++a) acc[5 + a] += p[SU_COMPLETED0 + a];
         for (int a = 0; a < 4; ++a) ret[a] += sf[(size_t)e * SF_WORDS + SF_SUM0 + a];
     }
@@ -372,6 +50,25 @@ __global__ __launch_bounds__(256) void k_stats_reduce(const uint32_t *__restrict
     }
 }
 
+// cz_reset_stats: zero the counters; steps already taken by episodes in flight must not be counted again
+__global__ void k_stats_clear(uint32_t *su, double *sf, const uint32_t *__restrict__ state, int RW, int N) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    uint32_t *p = su + (size_t)e * SU_WORDS;
+    const uint32_t *rec = state + (size_t)e * RW;
+    for (int j = 0; j < (int)SU_WORDS; ++j) p[j] = 0;
+    p[SU_STEPS] = (rec[W_STATUS] & ST_DONE) ? 0u : (uint32_t)(-(int)rec[W_T]);
+    for (int a = 0; a < 4; ++a) sf[(size_t)e * SF_WORDS + SF_SUM0 + a] = 0.0;
+}
+
+// cz_reset on envs whose episode is still running: their steps stay counted as env-steps
+__global__ void k_count_aborted(uint32_t *su, const uint32_t *__restrict__ state, int RW, long long env_begin, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *rec = state + (size_t)(env_begin + i) * RW;
+    if (!(rec[W_STATUS] & ST_DONE)) su[(size_t)(env_begin + i) * SU_WORDS + SU_STEPS] += rec[W_T];
+}
+
 // ======================================================================================================
 // host: handle + C-ABI
 // ======================================================================================================
@@ -380,12 +77,13 @@ struct cz_handle_s {
     cz_config cfg;
     Params P;
     hipStream_t stream = nullptr;
-    int opl = 1, cpl = 1;
+    Launchers kl;
     int n_layouts = 0, n_recipes = 0;
     uint32_t *d_state = nullptr, *d_lay_init = nullptr, *d_lay_desc = nullptr, *d_recipes = nullptr;
     uint32_t *d_stat_u = nullptr;
     double *d_stat_f = nullptr;
     cz_stats *d_stats_out = nullptr;
+    double *d_lut = nullptr;
     // staging for the host-pointer API
     int32_t *d_actions = nullptr;
     double *d_obs = nullptr, *d_rew = nullptr;
@@ -425,6 +123,12 @@ static int fail(cz_handle h, const char *fmt, ...) {
 
 extern "C" const char *cz_last_error(cz_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
 extern "C" int32_t cz_abi_version(void) { return 1; }
+// diagnostic builds only (tools/phase_profile.py): where the kernels write their s_memtime stamps
+extern "C" int cz_debug_set_stamps(cz_handle h, void *d_buf) {
+    if (!h) return 1;
+    h->P.stamps = (unsigned long long *)d_buf;
+    return 0;
+}
 extern "C" int32_t cz_sizeof_config(void) { return (int32_t)sizeof(cz_config); }
 extern "C" int32_t cz_sizeof_stats(void) { return (int32_t)sizeof(cz_stats); }
 extern "C" uint32_t cz_action(uint64_t seed, int64_t env_global, int32_t agent, uint32_t step, uint32_t n_actions) {
@@ -462,7 +166,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     memset(&P, 0, sizeof P);
     P.N = cfg->num_envs; P.A = cfg->num_agents; P.W = cfg->width; P.H = cfg->height; P.D = cfg->max_dyn; P.F = cfg->feat_len;
     const int CW = (C + 3) / 4;
-    P.dyn0_off = CELL_WORD0 + CW;
+    P.dyn0_off = CELL_WORD0 + CW;   // CELL_WORD0 = 8 header + 4 agents + 8 words of running returns
     P.dyn1_off = P.dyn0_off + P.D;
     P.RW = (P.dyn1_off + P.D + 15) / 16 * 16;
     P.scheme = cfg->action_scheme; P.max_steps = cfg->max_steps; P.end_all = cfg->end_condition_all ? 1 : 0;
@@ -470,9 +174,15 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     P.recipe_reward = cfg->recipe_reward; P.recipe_penalty = cfg->recipe_penalty; P.node_reward = cfg->recipe_node_reward;
     P.time_penalty_step = cfg->max_time_penalty / (double)cfg->max_steps;       // cooking_env.py:307
     P.T = 1;
-    h->opl = (P.D + 63) / 64;
-    h->cpl = (C <= 64) ? 1 : 4;
-    if (h->opl == 2 || h->cpl == 4) { h->opl = 2; h->cpl = 4; }
+    h->kl = (P.D <= 64 && C <= 64) ? launchers_small() : launchers_large();
+    {   // the reward of a step on which no recipe node changed: cooking_env.py:304-307 with zero deltas, same op order
+        double x = 0.0;
+        x += (double)0 * P.node_reward;
+        x += 0.0 * P.recipe_reward;
+        x += 0.0 * P.recipe_penalty;
+        x += P.time_penalty_step;
+        P.reward_idle = x;
+    }
     const size_t N = (size_t)P.N;
     HIPCHK(nullptr, hipMalloc(&h->d_state, N * P.RW * 4));
     HIPCHK(nullptr, hipMemsetAsync(h->d_state, 0, N * P.RW * 4, h->stream));
@@ -483,6 +193,20 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     HIPCHK(nullptr, hipMalloc(&h->d_stats_out, sizeof(cz_stats)));
     HIPCHK(nullptr, hipStreamSynchronize(h->stream));
     P.state = h->d_state; P.stat_u = h->d_stat_u; P.stat_f = h->d_stat_f;
+    {   // observation quotients: (x - ax) / W and (y - ay) / H for every possible difference, computed here with the same
+        // IEEE-754 double division Python's int / int true division performs (cooking_env.py:364-368)
+        double lut[LUT_SIZE];
+        for (int i = 0; i < LUT_SIZE; ++i) lut[i] = 0.0;
+        for (int i = 0; i < 2 * P.W - 1; ++i) lut[i] = (double)(i - (P.W - 1)) / (double)P.W;
+        for (int i = 0; i < 2 * P.H - 1; ++i) lut[LUT_Y0 + i] = (double)(i - (P.H - 1)) / (double)P.H;
+        lut[LUT_ZERO] = 0.0; lut[LUT_ONE] = 1.0;
+        HIPCHK(nullptr, hipMalloc(&h->d_lut, sizeof lut));
+        HIPCHK(nullptr, hipMemcpy(h->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+        P.lut = h->d_lut;
+        P.inv_w = (65536u + (uint32_t)P.W - 1u) / (uint32_t)P.W;
+        for (uint32_t c = 0; c < 1024; ++c)
+            if (((c * P.inv_w) >> 16) != c / (uint32_t)P.W) return fail(nullptr, "cz_create: internal: inexact cell division for W=%d", P.W);
+    }
     *out = h;
     return 0;
 }
@@ -496,7 +220,7 @@ extern "C" int cz_destroy(cz_handle h) {
         destroy_t f = (destroy_t)dlsym(h->rccl, "ncclCommDestroy");
         if (f) f(h->comm);
     }
-    void *ptrs[] = {h->d_state, h->d_lay_init, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out,
+    void *ptrs[] = {h->d_lut, h->d_state, h->d_lay_init, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out,
                     h->d_actions, h->d_obs, h->d_rew, h->d_term, h->d_trunc, h->d_gather};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -527,6 +251,24 @@ extern "C" int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->n_recipes = n;
     h->P.recipes = h->d_recipes;
+    // Carrying an object from cell to cell changes no co-location (hence no recipe mark) when at most two agents
+    // exist (they can never share a cell, cooking_world.py:206-221) and no recipe relates a dynamic-class node to a
+    // node of a walkable static class (Floor, Switch, Block) -- the only statics a carried object can be "at".
+    int sensitive = h->P.A > 2;
+    for (int i = 0; i < n && !sensitive; ++i) {
+        const uint32_t *row = table + (size_t)i * (1 + MAX_NODES);
+        for (uint32_t j = 0; j < row[0] && !sensitive; ++j) {
+            uint32_t cls = row[1 + j] & 0xFF, children = (row[1 + j] >> 16) & 0xFF;
+            for (uint32_t c = 0; c < row[0]; ++c) {
+                if (!((children >> c) & 1)) continue;
+                uint32_t ccls = row[1 + c] & 0xFF;
+                bool pw = cls == FLOOR || cls == SWITCH || cls == BLOCK, cw = ccls == FLOOR || ccls == SWITCH || ccls == BLOCK;
+                bool pd = cls >= 16 && cls < 32, cd = ccls >= 16 && ccls < 32;
+                if ((pw && cd) || (pd && cw)) sensitive = 1;
+            }
+        }
+    }
+    h->P.walk_touches = sensitive;
     return 0;
 }
 
@@ -536,16 +278,15 @@ extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const 
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->d_lay_init) HIPCHK(h, hipFree(h->d_lay_init));
     if (h->d_lay_desc) HIPCHK(h, hipFree(h->d_lay_desc));
-    // validate descriptors: refs must stay inside the LDS image
-    const int C = h->P.W * h->P.H;
+    // validate descriptors: halfword indices must address a slot / cell / agent of this batch, axis codes must exist
     for (size_t i = 0; i < (size_t)n * h->P.F; ++i) {
-        uint32_t op = obs_desc[i] & 0xFF, ref = obs_desc[i] >> 8;
-        bool ok = op <= OP_AG_ONE;
-        if (op == OP_CELL_ACTIVE || op == OP_CELL_WALK) ok = ok && (int)ref < C;
-        if (op >= OP_DYN_X && op <= OP_DYN_ONE) ok = ok && (int)ref < h->P.D;
-        if (op >= OP_AG_X) ok = ok && (int)ref < h->P.A;
-        if (op == OP_CONST_X) ok = ok && (int)ref < h->P.W;
-        if (op == OP_CONST_Y) ok = ok && (int)ref < h->P.H;
+        uint32_t off = obs_desc[i] & 0xFFFFu, code4 = obs_desc[i] >> 16;
+        uint32_t hw = off >> 1, code = code4 >> 2;
+        bool ok = !(off & 1u) && !(code4 & 3u) && (code <= 2 || (code >= 4 && code < 4 + 2 * (uint32_t)h->P.A));
+        if (hw < (uint32_t)IMG_CELL0) ok = ok && (int)(hw / 6) < h->P.D;
+        else if (hw < (uint32_t)IMG_AG0) ok = ok && (int)((hw - IMG_CELL0) / 4) < h->P.W * h->P.H;
+        else if (hw < (uint32_t)IMG_ZERO) ok = ok && (int)((hw - IMG_AG0) / 8) < h->P.A && ((hw - IMG_AG0) & 7u) < 7u;
+        else ok = ok && hw == (uint32_t)IMG_ZERO;
         if (!ok) return fail(h, "cz_load_layouts: bad observation descriptor %#x at %zu", obs_desc[i], i);
     }
     size_t b0 = (size_t)n * h->P.RW * 4, b1 = (size_t)n * h->P.F * 4;
@@ -588,11 +329,6 @@ static int ready(cz_handle h) {
     return 0;
 }
 
-template <class F1, class F2>
-static void dispatch(cz_handle h, F1 small, F2 large) {
-    if (h->opl == 1 && h->cpl == 1) small(); else large();
-}
-
 static int launch_step(cz_handle h, const Params &P) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->ktime) {
@@ -605,9 +341,7 @@ static int launch_step(cz_handle h, const Params &P) {
         h->kev_used += 2;
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
-    dispatch(h, [&] { hipLaunchKernelGGL((k_step<1, 1>), dim3(P.N), dim3(64), 0, h->stream, P); },
-             [&] { hipLaunchKernelGGL((k_step<2, 4>), dim3(P.N), dim3(64), 0, h->stream, P); });
-    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, h->kl.step(P, h->stream));
     if (h->ktime) HIPCHK(h, hipEventRecord(e1, h->stream));
     return 0;
 }
@@ -641,9 +375,9 @@ extern "C" int cz_reset(cz_handle h, int64_t b, int64_t c, const int32_t *layout
     size_t ob = (size_t)c * h->P.A * h->P.F * 8;
     if (obs) HIPCHK(h, hipMalloc(&d_obs, ob));
     Params P = h->P;
-    dispatch(h, [&] { hipLaunchKernelGGL((k_reset<1, 1>), dim3((unsigned)c), dim3(64), 0, h->stream, P, b, d_lay, d_rec, d_pool, d_obs); },
-             [&] { hipLaunchKernelGGL((k_reset<2, 4>), dim3((unsigned)c), dim3(64), 0, h->stream, P, b, d_lay, d_rec, d_pool, d_obs); });
-    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(k_count_aborted, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, h->stream, h->d_stat_u, h->d_state, h->P.RW,
+                       (long long)b, (int)c);
+    HIPCHK(h, h->kl.reset(P, h->stream, b, (int)c, d_lay, d_rec, d_pool, d_obs));
     if (obs) HIPCHK(h, hipMemcpyAsync(obs, d_obs, ob, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     (void)hipFree(d_lay); (void)hipFree(d_rec); (void)hipFree(d_pool);
@@ -661,9 +395,7 @@ extern "C" int cz_observe(cz_handle h, int64_t b, int64_t c, double *obs) {
     size_t ob = (size_t)c * h->P.A * h->P.F * 8;
     HIPCHK(h, hipMalloc(&d_obs, ob));
     Params P = h->P;
-    dispatch(h, [&] { hipLaunchKernelGGL((k_observe<1, 1>), dim3((unsigned)c), dim3(64), 0, h->stream, P, b, d_obs); },
-             [&] { hipLaunchKernelGGL((k_observe<2, 4>), dim3((unsigned)c), dim3(64), 0, h->stream, P, b, d_obs); });
-    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, h->kl.observe(P, h->stream, b, (int)c, d_obs));
     HIPCHK(h, hipMemcpyAsync(obs, d_obs, ob, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     (void)hipFree(d_obs);
@@ -781,7 +513,7 @@ extern "C" int cz_kernel_time_read(cz_handle h, double *total_ms, int64_t *launc
 extern "C" int cz_get_stats(cz_handle h, cz_stats *out) {
     if (!h || !out) return fail(h, "cz_get_stats: null argument");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(256), 0, h->stream, h->d_stat_u, h->d_stat_f, h->P.N, h->d_stats_out);
+    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(256), 0, h->stream, h->d_stat_u, h->d_stat_f, h->d_state, h->P.RW, h->P.N, h->d_stats_out);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(out, h->d_stats_out, sizeof(cz_stats), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -789,9 +521,10 @@ extern "C" int cz_get_stats(cz_handle h, cz_stats *out) {
 }
 extern "C" int cz_reset_stats(cz_handle h) {
     if (!h) return fail(nullptr, "null handle");
-    HIPCHK(h, hipMemsetAsync(h->d_stat_u, 0, (size_t)h->P.N * SU_WORDS * 4, h->stream));
-    // keep the running return of the episode in flight (SF_CUR), clear the finished-episode sums
-    HIPCHK(h, hipMemset2DAsync(h->d_stat_f + SF_SUM0, SF_WORDS * 8, 0, 4 * 8, (size_t)h->P.N, h->stream));
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    hipLaunchKernelGGL(k_stats_clear, dim3((h->P.N + 255) / 256), dim3(256), 0, h->stream, h->d_stat_u, h->d_stat_f, h->d_state,
+                       h->P.RW, h->P.N);
+    HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -837,7 +570,7 @@ extern "C" int cz_stats_allgather(cz_handle h, cz_stats *out) {
     if (!h || !out) return fail(h, "cz_stats_allgather: null argument");
     if (!h->comm) return fail(h, "cz_stats_allgather: communicator not initialised (cz_comm_init)");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(256), 0, h->stream, h->d_stat_u, h->d_stat_f, h->P.N, h->d_stats_out);
+    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(256), 0, h->stream, h->d_stat_u, h->d_stat_f, h->d_state, h->P.RW, h->P.N, h->d_stats_out);
     HIPCHK(h, hipGetLastError());
     typedef int (*fn_t)(const void *, void *, size_t, int, void *, hipStream_t);
     fn_t f = (fn_t)dlsym(h->rccl, "ncclAllGather");

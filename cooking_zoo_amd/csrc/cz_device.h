@@ -10,10 +10,14 @@
 //     ballot; a field of one object is a v_readlane; a mutation is a predicated write by the owning lane.
 //   * agents are resolved serially in index order (action_scheme3.py:15-16) -- semantics demand it --
 //     but each agent's work is O(1) wave instructions instead of O(objects) scans.
-//   * the feature-vector encode (cooking_env.py:352-373) is a per-layout descriptor table walk: lanes
-//     stride over the F output doubles, gather the referenced slot/cell from an LDS image of the final
-//     state, and store coalesced 8-byte values; x/W, y/H come from an LDS table of correctly rounded
-//     quotients (IEEE f64 division, done once per wave).
+//   * the step is instruction-issue bound (profiles/r01), so the common path is kept short: agent count and
+//     action scheme are compile-time, one rolled copy of the interaction code serves every agent, and the
+//     recipe graphs / free-flag normalisation are re-evaluated only when an object actually changed
+//     (both are pure functions of object state, so skipping them on untouched steps is exact).
+//   * the feature-vector encode (cooking_env.py:352-373) walks a per-layout descriptor table: lanes stride
+//     over the F output doubles, gather one word of an LDS image of the final state, turn it into an index
+//     into an LDS table of correctly rounded quotients d/W, d/H (IEEE f64 division, done once per wave)
+//     and the constants 0.0 / 1.0, and store coalesced 8-byte values.
 // Integer / indexing work only; no MFMA.  No CPU fallback exists in this file or its callers.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -25,7 +29,8 @@ constexpr int MAX_AGENTS = 4;
 constexpr int MAX_NODES = 8;
 constexpr int HDR_WORDS = 8;
 constexpr int AGENT_WORD0 = HDR_WORDS;
-constexpr int CELL_WORD0 = HDR_WORDS + MAX_AGENTS;
+constexpr int RET_WORD0 = HDR_WORDS + MAX_AGENTS;          // 4 x f64 running episode returns
+constexpr int CELL_WORD0 = RET_WORD0 + 2 * MAX_AGENTS;
 
 enum : uint32_t { FLOOR = 0, COUNTER, DELIVERSQUARE, SWITCH, BLOCK, CUTBOARD, BLENDER };
 enum : uint32_t { PLATE = 0, ONION, TOMATO, LETTUCE, CARROT, CUCUMBER, BANANA, APPLE, WATERMELON, BREAD };
@@ -35,11 +40,8 @@ enum : uint32_t { D_ALIVE = 1u << 24, D_CHOPPED = 2u << 24, D_MASHED = 4u << 24,
 enum : uint32_t { COND_NONE = 0, COND_CHOPPED, COND_MASHED, COND_NOT_CHOPPED, COND_NOT_MASHED };
 enum : uint32_t { W_T = 0, W_MARKS, W_LAYOUT, W_STATUS, W_EPISODE, W_RECIPES, W_POOL, W_RES1 };
 enum : uint32_t { ST_DONE = 1, ST_TERM = 2, ST_TRUNC = 4 };
-enum : uint32_t {
-    OP_ZERO = 0, OP_ONE, OP_CONST_X, OP_CONST_Y, OP_CELL_ACTIVE, OP_CELL_WALK, OP_DYN_X, OP_DYN_Y, OP_DYN_NOTDONE,
-    OP_DYN_DONE, OP_DYN_CHOPPED, OP_DYN_MASHED, OP_DYN_ONE, OP_AG_X, OP_AG_Y, OP_AG_O1, OP_AG_O2, OP_AG_O3, OP_AG_O4,
-    OP_AG_ONE
-};
+// observation descriptor (one u32 per feature): (image halfword index * 2) | (axis code * 4) << 16  -- soa.py
+constexpr int LUT_Y0 = 64, LUT_ZERO = 126, LUT_ONE = 127;   // + entries 128..255 = 0.0, the "absent" zone
 // per-env statistics: u32 words and doubles
 enum : uint32_t { SU_EPISODES = 0, SU_STEPS, SU_LENSUM, SU_TRUNC, SU_TERM, SU_COMPLETED0, SU_WORDS = 16 };
 enum : uint32_t { SF_CUR0 = 0, SF_SUM0 = 4, SF_WORDS = 8 };
@@ -58,15 +60,23 @@ struct Params {
     int64_t env_id_base;
     uint64_t seed;
     double recipe_reward, recipe_penalty, node_reward, time_penalty_step;
+    double reward_idle;            // the reward formula evaluated with no goal change (host, same op order)
+    const double *lut;             // [256] host-computed quotients: [i] (i-(W-1))/W, [64+i] (i-(H-1))/H, [126] 0, [127] 1, rest 0
+    uint32_t inv_w;                // ceil(65536 / W): c / W == (c * inv_w) >> 16 for every cell index c
     int32_t N, A, W, H, D, F, RW, scheme, max_steps, end_all, R, auto_reset, L;
     int32_t T;                     // fused steps per launch (1 for cz_step)
     uint32_t step0;
     int32_t dyn0_off, dyn1_off;    // word offsets inside a record
+    int32_t walk_touches;          // 1 if carrying an object across cells can change a recipe mark (see cz_load_recipes)
+    unsigned long long *stamps;    // diagnostic build only: [N][8] s_memtime stamps (nullptr in the shipped library)
 };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rdl(uint32_t v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// v_writelane_b32: clang 22 / ROCm 7.2 has no builtin for it; bind the LLVM intrinsic the way the HIP headers do
+extern "C" __device__ uint32_t __cz_writelane(uint32_t, uint32_t, uint32_t) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ uint32_t wrl(uint32_t value, int lane, uint32_t into) { return __cz_writelane(value, (uint32_t)lane, into); }
 
 // counter-based action stream (host mirror: cz_action in cz_api.hip, oracle mirror: czo_action)
 __host__ __device__ inline uint32_t action_hash(uint64_t seed, int64_t env_global, int agent, uint32_t step, uint32_t n) {
@@ -114,6 +124,7 @@ struct Mask {
         return r;
     }
     __device__ __forceinline__ uint64_t word(int k) const {
+        if (N == 1) return w[0];
         uint64_t v = 0;
 #pragma unroll
         for (int j = 0; j < N; ++j)
@@ -124,12 +135,12 @@ struct Mask {
     __device__ __forceinline__ void set(int s) {
 #pragma unroll
         for (int j = 0; j < N; ++j)
-            if (j == (s >> 6)) w[j] |= 1ull << (s & 63);
+            if (N == 1 || j == (s >> 6)) w[j] |= 1ull << (s & 63);
     }
     __device__ __forceinline__ void clear(int s) {
 #pragma unroll
         for (int j = 0; j < N; ++j)
-            if (j == (s >> 6)) w[j] &= ~(1ull << (s & 63));
+            if (N == 1 || j == (s >> 6)) w[j] &= ~(1ull << (s & 63));
     }
     __device__ __forceinline__ Mask operator&(const Mask &o) const {
         Mask r;
@@ -152,26 +163,53 @@ struct Mask {
 };
 
 // One env's world, resident in registers for the whole step (or the whole fused rollout).
-template <int OPL, int CPL>
+template <int OPL, int CPL, int NA>
 struct Env {
     uint32_t d0[OPL], d1[OPL];     // per lane: slots lane + 64k
     uint32_t cell[CPL];            // per lane: cells lane + 64k
-    int ax[MAX_AGENTS], ay[MAX_AGENTS], ao[MAX_AGENTS], ah[MAX_AGENTS];   // uniform; ah = held slot or -1
+    int ax[NA], ay[NA], ao[NA], ah[NA];                                   // uniform; ah = held slot or -1
     uint32_t t, marks, layout, status, episode, recipes, pool;            // uniform header
 };
 
 struct Ctx {                       // wave-uniform geometry + this lane's index
-    int A, W, H, D, lane;
+    int W, H, D, C, lane;
 };
 
-template <int OPL, int CPL>
+struct Dirty {                     // what this step changed (uniform)
+    uint32_t pressed;              // a Switch was stepped on                    -> Blocks flip at end of step
+    uint32_t touched;              // some object moved or changed state         -> recipe marks must be re-evaluated
+    uint32_t interacted;           // containment / free flags may have changed  -> free-flag normalisation needed
+    uint32_t cells;                // some mutable cell bit changed              -> the cell bytes must be written back
+    uint32_t moved;                // a held object was carried to another cell  -> objects must be written back
+};
+
+template <int NA>
+__device__ __forceinline__ int sel(const int (&a)[NA], int i) {
+    int v = a[0];
+#pragma unroll
+    for (int k = 1; k < NA; ++k)
+        if (i == k) v = a[k];
+    return v;
+}
+template <int NA>
+__device__ __forceinline__ void put(int (&a)[NA], int i, int v) {
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+        if (NA == 1 || i == k) a[k] = v;
+}
+
+// dx + 1 / dy + 1 of get_target_location (cooking_world.py:172-184), two bits per action code 0..7
+constexpr uint32_t DX_TABLE = 0x5561u, DY_TABLE = 0x5495u;
+
+template <int OPL, int CPL, int NA, int SCHEME>
 struct Ops {
-    using E = Env<OPL, CPL>;
+    using E = Env<OPL, CPL, NA>;
     using OM = Mask<OPL>;
     using CM = Mask<CPL>;
 
     // ---- uniform reads / predicated writes of one slot / one cell ---------------------------------------
     static __device__ __forceinline__ uint32_t slot_d0(const E &e, int s) {
+        if (OPL == 1) return rdl(e.d0[0], s);
         uint32_t v = 0;
 #pragma unroll
         for (int k = 0; k < OPL; ++k)
@@ -179,22 +217,26 @@ struct Ops {
         return v;
     }
     static __device__ __forceinline__ uint32_t cell_at(const E &e, int c) {
+        if (CPL == 1) return rdl(e.cell[0], c);
         uint32_t v = 0;
 #pragma unroll
         for (int k = 0; k < CPL; ++k)
             if ((c >> 6) == k) v = rdl(e.cell[k], c & 63);
         return v;
     }
-    static __device__ __forceinline__ void cell_update(E &e, const Ctx &cx, int c, uint32_t clear_bits, uint32_t xor_bits) {
+    static __device__ __forceinline__ void cell_update(E &e, const Ctx &cx, int c, uint32_t clear_bits, uint32_t xor_bits, Dirty &dt) {
 #pragma unroll
         for (int k = 0; k < CPL; ++k)
-            if ((c >> 6) == k && cx.lane == (c & 63)) e.cell[k] = (e.cell[k] & ~clear_bits) ^ xor_bits;
+            if ((CPL == 1 || (c >> 6) == k) && cx.lane == (c & 63)) e.cell[k] = (e.cell[k] & ~clear_bits) ^ xor_bits;
+        dt.cells = 1;
     }
-    // cooking_world.py:223-227 square_walkable (Floor, Switch: yes; Block: its bit; everything else: no)
-    static __device__ __forceinline__ bool walkable(uint32_t cv) {
-        uint32_t ty = cv & CELL_TYPE;
-        return ty == FLOOR || ty == SWITCH || (ty == BLOCK && (cv & CELL_WALK));
-    }
+    // cooking_world.py:223-227 square_walkable: Floor (0) and Switch (3) always, Block (4) by its bit (only Blocks
+    // ever carry CELL_WALK), everything else never
+    static __device__ __forceinline__ bool walkable(uint32_t cv) { return ((0x9u >> (cv & CELL_TYPE)) | (cv >> 6)) & 1u; }
+    // statics that can hold objects: Counter 1, Deliversquare 2, Cutboard 5, Blender 6.  Interactions aimed at a Floor,
+    // Switch or Block cell are no-ops in every case (nothing is ever placed there; the reference's agent-at-location
+    // guard, cooking_world.py:116,140,158, only ever fires for such cells), so they return early on the type.
+    static __device__ __forceinline__ bool holds_objects(uint32_t ty) { return (0x66u >> ty) & 1u; }
 
     // ---- ballots over object lanes ----------------------------------------------------------------------
     template <class F>
@@ -204,25 +246,14 @@ struct Ops {
         for (int k = 0; k < OPL; ++k) m.w[k] = ballot(pred(e.d0[k], e.d1[k]));
         return m;
     }
-    // get_objects_at(location, DynamicObject) cooking_world.py:232-241 as a slot mask (slot order == list order)
-    static __device__ __forceinline__ OM dyn_at(const E &e, uint32_t xy) {
-        return oballot(e, [=](uint32_t a, uint32_t) { return (a & D_ALIVE) && (a & 0xFFFFu) == xy; });
-    }
     static __device__ __forceinline__ OM content_of(const E &e, int plate) {   // Plate.content membership
         uint32_t tag = (uint32_t)(plate + 1);
         return oballot(e, [=](uint32_t a, uint32_t b) { return (a & D_ALIVE) && (b & 0xFFu) == tag; });
     }
-    static __device__ __forceinline__ OM held_mask(const E &e, const Ctx &cx) {
-        OM m = OM::zero();
-#pragma unroll
-        for (int a = 0; a < MAX_AGENTS; ++a)
-            if (a < cx.A && e.ah[a] >= 0) m.set(e.ah[a]);
-        return m;
-    }
-    // static.content == objects on the cell that are neither inside a plate nor held (soa.py header)
-    static __device__ __forceinline__ OM direct_at(const E &e, const Ctx &cx, uint32_t xy) {
-        OM m = oballot(e, [=](uint32_t a, uint32_t b) { return (a & D_ALIVE) && (a & 0xFFFFu) == xy && (b & 0xFFu) == 0; });
-        return m.andnot(held_mask(e, cx));
+    // static.content of a cell that holds objects == objects there that are not inside a plate (agents never stand on
+    // such a cell, so nothing there is "held")
+    static __device__ __forceinline__ OM direct_at(const E &e, uint32_t xy) {
+        return oballot(e, [=](uint32_t a, uint32_t b) { return (a & (D_ALIVE | 0xFFFFu)) == (D_ALIVE | xy) && (b & 0xFFu) == 0; });
     }
     // Object.move_to / Plate.move_to (abstract_classes.py:20, world_objects.py:393-396): slot s and, when it is a
     // plate, everything inside it
@@ -239,22 +270,6 @@ struct Ops {
         for (int k = 0; k < OPL; ++k)
             if (cx.lane + 64 * k == s) e.d0[k] |= bits;
     }
-    static __device__ __forceinline__ bool agent_at(const E &e, const Ctx &cx, int x, int y) {
-        bool r = false;
-#pragma unroll
-        for (int a = 0; a < MAX_AGENTS; ++a)
-            if (a < cx.A && e.ax[a] == x && e.ay[a] == y) r = true;
-        return r;
-    }
-    // cooking_world.py:172-184 get_target_location
-    static __device__ __forceinline__ void target(int x, int y, int action, int &tx, int &ty) {
-        tx = x + (action == 2) - (action == 1);
-        ty = y + (action == 3) - (action == 4);
-    }
-    static __device__ __forceinline__ bool in_bounds(const Ctx &cx, int x, int y) {
-        return x >= 0 && y >= 0 && x < cx.W && y < cx.H;
-    }
-
     // Plate.add_content (world_objects.py:398-406): append s to plate p: every item free=False, the new last True
     static __device__ __forceinline__ void plate_add(E &e, const Ctx &cx, int p, int s, int cnt) {
         uint32_t tag = (uint32_t)(p + 1);
@@ -268,14 +283,18 @@ struct Ops {
         }
     }
 
-    // cooking_world.py:243-261 attempt_merge (first matching branch only, no fall-through on refusal)
-    static __device__ __forceinline__ void attempt_merge(E &e, const Ctx &cx, int i, const OM &dyn, int lx, int ly,
-                                                         uint32_t sv) {
+    // One agent's view while it acts (uniform scalars, written back by the caller)
+    struct Me { int x, y, o, h; };
+
+    // cooking_world.py:243-261 attempt_merge (first matching branch only, no fall-through on refusal).
+    // dyn = objects at the target cell, sv = its cell byte, (lx, ly) the cell
+    static __device__ __forceinline__ void attempt_merge(E &e, const Ctx &cx, Me &me, const OM &dyn, int lx, int ly, int c,
+                                                         uint32_t sv, Dirty &dt) {
         const uint32_t lxy = (uint32_t)lx | ((uint32_t)ly << 8);
-        const int held = e.ah[i];
+        const int held = me.h;
         const uint32_t hw = slot_d0(e, held);
         const uint32_t hcls = (hw >> 16) & 0xFF;
-        OM plates = dyn & oballot(e, [](uint32_t a, uint32_t) { return ((a >> 16) & 0xFF) == PLATE; });
+        OM plates = dyn & oballot(e, [](uint32_t a, uint32_t) { return (a & 0xFF0000u) == (PLATE << 16); });
         int np = plates.count();
         if (np == 1) {
             int p = plates.first();
@@ -284,19 +303,21 @@ struct Ops {
             if (hcls != PLATE && (hw & D_DONE) && cnt < 64) {
                 plate_add(e, cx, p, held, cnt);
                 move_obj(e, cx, held, lxy);                      // Agent.put_down world_objects.py:789-791
-                e.ah[i] = -1;
+                me.h = -1;
+                dt.touched = 1;
             }
         } else if (hcls == PLATE && dyn.any()) {
             int o = dyn.last();                                   // pick_index = -1
             uint32_t ow = slot_d0(e, o);
             int cnt = content_of(e, held).count();
-            if (((ow >> 16) & 0xFF) != PLATE && (ow & D_DONE) && cnt < 64) {
+            if ((ow & 0xFF0000u) != (PLATE << 16) && (ow & D_DONE) && cnt < 64) {
                 plate_add(e, cx, held, o, cnt);
-                move_obj(e, cx, o, (uint32_t)e.ax[i] | ((uint32_t)e.ay[i] << 8));
+                move_obj(e, cx, o, (uint32_t)me.x | ((uint32_t)me.y << 8));
+                dt.touched = 1;
                 // static_object.content.remove(o) is implicit: o now carries a container tag
             }
         } else {
-            int ncontent = direct_at(e, cx, lxy).count();
+            int ncontent = (dyn & oballot(e, [](uint32_t, uint32_t b) { return (b & 0xFFu) == 0; })).count();
             uint32_t ty = sv & CELL_TYPE;
             bool ok = false;
             if (ty == COUNTER || ty == DELIVERSQUARE) {                            // world_objects.py:64-66,107-108
@@ -307,61 +328,53 @@ struct Ops {
                 ok = (hcls == CARROT || hcls == BANANA) && !(sv & CELL_TOGGLE) && ncontent + 1 <= 1 && !(hw & D_MASHED);
             }
             if (ok) {
-                if (ty == CUTBOARD || ty == BLENDER) cell_update(e, cx, ly * cx.W + lx, CELL_READY, CELL_READY);
+                if (ty >= CUTBOARD) cell_update(e, cx, c, CELL_READY, CELL_READY, dt);
                 // add_content: the content list was empty, so the new item is its last element: free=True
                 slot_or(e, cx, held, D_FREE);
                 move_obj(e, cx, held, lxy);
-                e.ah[i] = -1;
+                me.h = -1;
+                dt.touched = 1;
             }
         }
     }
 
-    // cooking_world.py:114-136 resolve_primary_interaction
-    static __device__ __forceinline__ void primary(E &e, const Ctx &cx, int i) {
-        int lx, ly;
-        target(e.ax[i], e.ay[i], e.ao[i], lx, ly);
-        if (!in_bounds(cx, lx, ly)) return;             // reference: IndexError (scheme1 facing off-grid); build: no-op
-        if (agent_at(e, cx, lx, ly)) return;
-        const uint32_t lxy = (uint32_t)lx | ((uint32_t)ly << 8);
-        OM dyn = dyn_at(e, lxy);
-        const int c = ly * cx.W + lx;
-        const uint32_t sv = cell_at(e, c);
-        if (e.ah[i] < 0) {
+    // cooking_world.py:114-136 resolve_primary_interaction on cell (lx, ly) = c whose byte is sv (a cell that holds objects)
+    static __device__ __forceinline__ void primary(E &e, const Ctx &cx, Me &me, int lx, int ly, int c, uint32_t sv, const OM &dyn,
+                                                   Dirty &dt) {
+        if (me.h < 0) {
             if (!dyn.any()) return;
-            OM direct = direct_at(e, cx, lxy);
+            dt.interacted = 1;
+            OM direct = dyn & oballot(e, [](uint32_t, uint32_t b) { return (b & 0xFFu) == 0; });
             int ncontent = direct.count();
             uint32_t ty = sv & CELL_TYPE;
             // static_object.releases() with its side effects: world_objects.py:117-118,275-278,340-346
             bool rel = true;
             if (ty == DELIVERSQUARE) rel = false;
             else if (ty == CUTBOARD) {
-                if (ncontent == 1) cell_update(e, cx, c, CELL_READY, 0);
+                if (ncontent == 1 && (sv & CELL_READY)) cell_update(e, cx, c, CELL_READY, 0, dt);
             } else if (ty == BLENDER) {
                 rel = !(sv & CELL_TOGGLE);
-                if (rel && ncontent - 1 == 0) cell_update(e, cx, c, CELL_READY, 0);
+                if (rel && ncontent - 1 == 0 && (sv & CELL_READY)) cell_update(e, cx, c, CELL_READY, 0, dt);
             }
             if (rel) {
                 OM fr = dyn & oballot(e, [](uint32_t a, uint32_t) { return (a & D_FREE) != 0; });
                 int grab = fr.any() ? fr.first() : dyn.last();
                 if (direct.test(grab)) {                        // object_to_grab in static_object.content
-                    e.ah[i] = grab;                             // Agent.grab world_objects.py:785-787
-                    move_obj(e, cx, grab, (uint32_t)e.ax[i] | ((uint32_t)e.ay[i] << 8));
+                    me.h = grab;                                // Agent.grab world_objects.py:785-787
+                    move_obj(e, cx, grab, (uint32_t)me.x | ((uint32_t)me.y << 8));
+                    dt.touched = 1;
                 }
             }
         } else {
-            attempt_merge(e, cx, i, dyn, lx, ly, sv);
+            dt.interacted = 1;
+            attempt_merge(e, cx, me, dyn, lx, ly, c, sv, dt);
         }
     }
 
     // cooking_world.py:138-154 resolve_interaction_pick_up_special (scheme1)
-    static __device__ __forceinline__ void pick_up_special(E &e, const Ctx &cx, int i) {
-        int lx, ly;
-        target(e.ax[i], e.ay[i], e.ao[i], lx, ly);
-        if (!in_bounds(cx, lx, ly)) return;
-        if (agent_at(e, cx, lx, ly)) return;
-        OM dyn = dyn_at(e, (uint32_t)lx | ((uint32_t)ly << 8));
-        if (e.ah[i] >= 0 || !dyn.any()) return;
-        OM plates = dyn & oballot(e, [](uint32_t a, uint32_t) { return ((a >> 16) & 0xFF) == PLATE; });
+    static __device__ __forceinline__ void pick_up_special(E &e, const Ctx &cx, Me &me, const OM &dyn, Dirty &dt) {
+        if (me.h >= 0 || !dyn.any()) return;
+        OM plates = dyn & oballot(e, [](uint32_t a, uint32_t) { return (a & 0xFF0000u) == (PLATE << 16); });
         if (plates.count() != 1) return;
         int p = plates.first();
         OM cm = content_of(e, p);
@@ -373,31 +386,27 @@ struct Ops {
 #pragma unroll
         for (int k = 0; k < OPL; ++k)
             if (cx.lane + 64 * k == s) e.d1[k] = 0;        // content.pop(-1)
-        e.ah[i] = s;
-        move_obj(e, cx, s, (uint32_t)e.ax[i] | ((uint32_t)e.ay[i] << 8));
+        me.h = s;
+        move_obj(e, cx, s, (uint32_t)me.x | ((uint32_t)me.y << 8));
+        dt.touched = 1;
+        dt.interacted = 1;
     }
 
     // cooking_world.py:156-170 resolve_execute_action; Cutboard.action world_objects.py:250-269;
     // ChopFood.chop abstract_classes.py:250-254; Bread.chop world_objects.py:738-745; Blender.action :356-360
-    static __device__ __forceinline__ void execute(E &e, const Ctx &cx, int i) {
-        int lx, ly;
-        target(e.ax[i], e.ay[i], e.ao[i], lx, ly);
-        if (!in_bounds(cx, lx, ly)) return;
-        if (agent_at(e, cx, lx, ly)) return;
-        const int c = ly * cx.W + lx;
-        const uint32_t sv = cell_at(e, c);
+    static __device__ __forceinline__ void execute(E &e, const Ctx &cx, int lx, int ly, int c, uint32_t sv, const OM &dyn, Dirty &dt) {
         const uint32_t ty = sv & CELL_TYPE;
         if (ty == CUTBOARD) {
             if (!(sv & CELL_READY)) return;
             const uint32_t lxy = (uint32_t)lx | ((uint32_t)ly << 8);
-            OM fresh = direct_at(e, cx, lxy) & oballot(e, [](uint32_t a, uint32_t) { return !(a & D_CHOPPED); });
+            OM fresh = dyn & oballot(e, [](uint32_t a, uint32_t b) { return (b & 0xFFu) == 0 && !(a & D_CHOPPED); });
             int f = fresh.first();                          // first content item whose chop() executes
             if (f < 0) return;                              // reference falls off Cutboard.action (TypeError); unreachable
             uint32_t fw = slot_d0(e, f);
             slot_or(e, cx, f, D_CHOPPED);
-            if (((fw >> 16) & 0xFF) == BREAD) {
+            if ((fw & 0xFF0000u) == (BREAD << 16)) {
                 // the clone: first not-alive Bread slot (head-room follows the originals), born chopped and free
-                OM spare = oballot(e, [](uint32_t a, uint32_t) { return !(a & D_ALIVE) && ((a >> 16) & 0xFF) == BREAD; });
+                OM spare = oballot(e, [](uint32_t a, uint32_t) { return (a & (D_ALIVE | 0xFF0000u)) == (BREAD << 16); });
                 int n = spare.first();
 #pragma unroll
                 for (int k = 0; k < OPL; ++k)
@@ -406,155 +415,176 @@ struct Ops {
                         e.d1[k] = 0;
                     }
             }
-            cell_update(e, cx, c, CELL_READY, 0);
+            cell_update(e, cx, c, CELL_READY, 0, dt);
+            dt.touched = 1;
+            dt.interacted = 1;
         } else if (ty == BLENDER) {
-            if (sv & CELL_READY) cell_update(e, cx, c, 0, CELL_TOGGLE);
+            if (sv & CELL_READY) cell_update(e, cx, c, 0, CELL_TOGGLE, dt);
         }
-    }
-
-    // action_scheme3.py:26-34 resolve_walking_action; returns whether the agent "moved" (also true for a == 0 on a
-    // walkable cell: move_to(own cell) creates a new tuple, action_scheme3.py:22)
-    static __device__ __forceinline__ bool walk(E &e, const Ctx &cx, int i, int action, uint32_t &pressed) {
-        int tx, ty;
-        target(e.ax[i], e.ay[i], action, tx, ty);
-        const int c = ty * cx.W + tx;
-        const uint32_t cv = cell_at(e, c);
-        if (!walkable(cv)) return false;
-        e.ax[i] = tx;
-        e.ay[i] = ty;                                                   // Agent.move_to world_objects.py:793-796
-        if (e.ah[i] >= 0) move_obj(e, cx, e.ah[i], (uint32_t)tx | ((uint32_t)ty << 8));
-        if ((cv & CELL_TYPE) == SWITCH) {                               // Switch.add_content :159-163
-            cell_update(e, cx, c, 0, CELL_ACTIVE);
-            pressed = 1;
-        }
-        return true;
     }
 
     // action_scheme3.py:4-43 / action_scheme1.py:4-40 perform_agent_actions (+ check_inbounds
     // cooking_world.py:192-204, check_collisions :206-221)
-    static __device__ __forceinline__ void perform_agent_actions(E &e, const Ctx &cx, const int (&raw)[MAX_AGENTS], int scheme,
-                                                                 uint32_t &pressed) {
-        int cleaned[MAX_AGENTS], coll[MAX_AGENTS], ex[MAX_AGENTS], ey[MAX_AGENTS];
-        bool wk[MAX_AGENTS];
+    static __device__ __forceinline__ void perform_agent_actions(E &e, const Ctx &cx, const int (&raw)[NA], Dirty &dt) {
+        int act[NA], tx[NA], ty[NA], tcv[NA];        // cleaned action, its target cell and that cell's byte
+        int ex[NA], ey[NA];
+        bool wk[NA];
 #pragma unroll
-        for (int a = 0; a < MAX_AGENTS; ++a) {
-            cleaned[a] = 0; coll[a] = 0; ex[a] = -1; ey[a] = -1; wk[a] = false;
-            if (a >= cx.A) continue;
-            int act = raw[a];
-            if (act >= 1 && act <= 4) e.ao[a] = act;                    // change_orientation before any filtering
-            // check_inbounds
-            if (act != 0 && act != 5) {
-                int tx, ty;
-                target(e.ax[a], e.ay[a], act, tx, ty);
-                if (tx > cx.W - 1 || tx < 0) act = 0;
-                if (ty > cx.H - 1 || ty < 0) act = 0;
-            }
-            cleaned[a] = act;
-            int tx, ty;
-            target(e.ax[a], e.ay[a], act, tx, ty);
-            wk[a] = walkable(cell_at(e, ty * cx.W + tx));
-            ex[a] = wk[a] ? tx : e.ax[a];
-            ey[a] = wk[a] ? ty : e.ay[a];
+        for (int a = 0; a < NA; ++a) {
+            int r = raw[a];
+            if ((uint32_t)(r - 1) < 4u) e.ao[a] = r;                    // change_orientation before any filtering
+            int x = e.ax[a] + (int)((DX_TABLE >> (2 * r)) & 3u) - 1;
+            int y = e.ay[a] + (int)((DY_TABLE >> (2 * r)) & 3u) - 1;
+            // check_inbounds (0 and 5 pass; 6 and 7 aim at the own cell, always inside)
+            if ((uint32_t)x >= (uint32_t)cx.W || (uint32_t)y >= (uint32_t)cx.H) { r = 0; x = e.ax[a]; y = e.ay[a]; }
+            act[a] = r; tx[a] = x; ty[a] = y;
+            tcv[a] = (int)cell_at(e, y * cx.W + x);
+            wk[a] = walkable((uint32_t)tcv[a]);
+            ex[a] = wk[a] ? x : e.ax[a];
+            ey[a] = wk[a] ? y : e.ay[a];
         }
+        if (NA > 1) {
 #pragma unroll
-        for (int a = 0; a < MAX_AGENTS; ++a) {
-            if (a >= cx.A) continue;
-            bool clash = false;
+            for (int a = 0; a < NA; ++a) {
+                bool clash = false;
 #pragma unroll
-            for (int b = 0; b < MAX_AGENTS; ++b)
-                if (b != a && b < cx.A && ex[b] == ex[a] && ey[b] == ey[a]) clash = true;
-            coll[a] = (clash && wk[a]) ? 0 : cleaned[a];
-        }
-#pragma unroll
-        for (int a = 0; a < MAX_AGENTS; ++a) {
-            if (a >= cx.A) continue;
-            const int act = coll[a];
-            if (scheme == 3) {
-                bool moved = walk(e, cx, a, act, pressed);
-                if (!moved && act != 0) {
-                    // action_scheme3.py:37-43 resolve_interaction: ActionObject with a not-done item -> execute
-                    int tx, ty;
-                    target(e.ax[a], e.ay[a], act, tx, ty);
-                    uint32_t sv = cell_at(e, ty * cx.W + tx);
-                    uint32_t ty_ = sv & CELL_TYPE;
-                    OM dyn = dyn_at(e, (uint32_t)tx | ((uint32_t)ty << 8));
-                    OM notdone = dyn & oballot(e, [](uint32_t w, uint32_t) { return !(w & D_DONE); });
-                    if ((ty_ == CUTBOARD || ty_ == BLENDER) && notdone.any()) execute(e, cx, a);
-                    else primary(e, cx, a);
+                for (int b = 0; b < NA; ++b)
+                    if (b != a && ex[b] == ex[a] && ey[b] == ey[a]) clash = true;
+                if (clash && wk[a] && act[a] != 0) {                    // cancelled: the agent now "walks" onto its own cell
+                    act[a] = 0; tx[a] = e.ax[a]; ty[a] = e.ay[a];
+                    tcv[a] = (int)cell_at(e, ty[a] * cx.W + tx[a]);
                 }
-            } else {
-                if (act >= 1 && act <= 4) walk(e, cx, a, act, pressed);
-                else if (act == 5) primary(e, cx, a);
-                else if (act == 6) pick_up_special(e, cx, a);
-                else if (act == 7) execute(e, cx, a);
             }
+        }
+#pragma nounroll
+        for (int a = 0; a < NA; ++a) {
+            const int ac = sel<NA>(act, a);
+            const int lx = sel<NA>(tx, a), ly = sel<NA>(ty, a);
+            const int c = ly * cx.W + lx;
+            Me me{sel<NA>(e.ax, a), sel<NA>(e.ay, a), sel<NA>(e.ao, a), sel<NA>(e.ah, a)};
+            // cell types and Block walkability cannot change before the end of the step, so the byte read in the
+            // pre-pass still decides "walkable"; READY / TOGGLE bits may have been changed by an earlier agent
+            const uint32_t cv0 = (uint32_t)sel<NA>(tcv, a);
+            const bool is_walk = SCHEME == 3 || (uint32_t)(ac - 1) < 4u;
+            if (is_walk && walkable(cv0)) {
+                // action_scheme3.py:26-34 resolve_walking_action (scheme3: also for action 0, re-pressing a Switch)
+                if (me.h >= 0 && ac != 0) {                             // Agent.move_to world_objects.py:793-796
+                    move_obj(e, cx, me.h, (uint32_t)lx | ((uint32_t)ly << 8));
+                    dt.moved = 1;
+                }
+                me.x = lx; me.y = ly;
+                if ((cv0 & CELL_TYPE) == SWITCH) {                      // Switch.add_content :159-163
+                    cell_update(e, cx, c, 0, CELL_ACTIVE, dt);
+                    dt.pressed = 1;
+                }
+            } else if (SCHEME == 3 ? ac != 0 : ac >= 5) {
+                // the cell in front (scheme3: the bumped cell; scheme1: by orientation, may be off-grid)
+                int fx = lx, fy = ly, fc = c;
+                uint32_t sv;
+                bool ok = true;
+                if (SCHEME != 3) {
+                    fx = me.x + (int)((DX_TABLE >> (2 * me.o)) & 3u) - 1;
+                    fy = me.y + (int)((DY_TABLE >> (2 * me.o)) & 3u) - 1;
+                    ok = (uint32_t)fx < (uint32_t)cx.W && (uint32_t)fy < (uint32_t)cx.H;   // reference: IndexError; build: no-op
+                    fc = fy * cx.W + fx;
+                }
+                sv = ok ? cell_at(e, fc) : 0u;
+                if (ok && holds_objects(sv & CELL_TYPE)) {
+                    const uint32_t fxy = (uint32_t)fx | ((uint32_t)fy << 8);
+                    // get_objects_at(location, DynamicObject) cooking_world.py:232-241 as a slot mask
+                    OM dyn = oballot(e, [=](uint32_t w, uint32_t) { return (w & (D_ALIVE | 0xFFFFu)) == (D_ALIVE | fxy); });
+                    if (SCHEME == 3) {
+                        // action_scheme3.py:37-43: ActionObject with a not-done item -> execute, else primary
+                        bool exec = false;
+                        if ((sv & CELL_TYPE) >= CUTBOARD)
+                            exec = (dyn & oballot(e, [](uint32_t w, uint32_t) { return !(w & D_DONE); })).any();
+                        if (exec) execute(e, cx, fx, fy, fc, sv, dyn, dt);
+                        else primary(e, cx, me, fx, fy, fc, sv, dyn, dt);
+                    } else {
+                        if (ac == 5) primary(e, cx, me, fx, fy, fc, sv, dyn, dt);
+                        else if (ac == 6) pick_up_special(e, cx, me, dyn, dt);
+                        else execute(e, cx, fx, fy, fc, sv, dyn, dt);
+                    }
+                }
+            }
+            put<NA>(e.ax, a, me.x);
+            put<NA>(e.ay, a, me.y);
+            put<NA>(e.ah, a, me.h);
         }
     }
 
     // cooking_world.py:77-88 progress_world (+ Blender.process world_objects.py:321-335, BlenderFood.blend
     // abstract_classes.py:266-273) and :90-92 resolve_linked_interactions
-    static __device__ __forceinline__ void progress_and_link(E &e, const Ctx &cx, uint32_t pressed) {
-        // running blenders
+    static __device__ __forceinline__ void progress_and_link(E &e, const Ctx &cx, Dirty &dt) {
+        // running blenders (rare: a toggle set in this step, or a scheme1 blender stuck on)
         CM running;
 #pragma unroll
         for (int k = 0; k < CPL; ++k)
-            running.w[k] = ballot((e.cell[k] & CELL_TYPE) == BLENDER && (e.cell[k] & CELL_TOGGLE) &&
-                                  (cx.lane + 64 * k) < cx.W * cx.H);
+            running.w[k] = ballot((e.cell[k] & (CELL_TYPE | CELL_TOGGLE)) == (BLENDER | CELL_TOGGLE));
         while (running.any()) {
             int c = running.first();
             running.clear(c);
-            uint32_t xy = (uint32_t)(c % cx.W) | ((uint32_t)(c / cx.W) << 8);
-            OM content = direct_at(e, cx, xy);
+            uint32_t y = (uint32_t)c / (uint32_t)cx.W;
+            uint32_t xy = ((uint32_t)c - y * (uint32_t)cx.W) | (y << 8);
+            OM content = direct_at(e, xy);
             if (content.any()) {
 #pragma unroll
                 for (int k = 0; k < OPL; ++k)
                     if (((content.w[k] >> cx.lane) & 1) && !(e.d0[k] & D_DONE)) e.d0[k] |= D_MASHED;
                 OM mashed = content & oballot(e, [](uint32_t a, uint32_t) { return (a & D_MASHED) != 0; });
-                if (mashed.count() == content.count()) cell_update(e, cx, c, CELL_READY | CELL_TOGGLE, 0);
+                if (mashed.count() == content.count()) cell_update(e, cx, c, CELL_READY | CELL_TOGGLE, 0, dt);
+                dt.touched = 1;
+                dt.interacted = 1;
             }
         }
-        // free-flag normalisation: every container with content: all False, last True.
+        // free-flag normalisation (every container with content: all False, last True).  A pure function of the
+        // containment relations, so it is a no-op on steps without an interaction and skipped there.
         //  * on a static: the item is alone (free) except on a Cutboard carrying Bread + clone
         //  * inside a plate: free iff it is the last appended (seq == count-1)
         //  * held directly by an agent: untouched
-        OM held = held_mask(e, cx);
+        if (dt.interacted) {
+            OM held = OM::zero();
 #pragma unroll
-        for (int k = 0; k < OPL; ++k) {
-            bool on_static = (e.d0[k] & D_ALIVE) && (e.d1[k] & 0xFFu) == 0 && !((held.w[k] >> cx.lane) & 1);
-            if (on_static) e.d0[k] |= D_FREE;
-        }
-        CM boards;
+            for (int a = 0; a < NA; ++a)
+                if (e.ah[a] >= 0) held.set(e.ah[a]);
 #pragma unroll
-        for (int k = 0; k < CPL; ++k)
-            boards.w[k] = ballot((e.cell[k] & CELL_TYPE) == CUTBOARD && (cx.lane + 64 * k) < cx.W * cx.H);
-        while (boards.any()) {
-            int c = boards.first();
-            boards.clear(c);
-            uint32_t xy = (uint32_t)(c % cx.W) | ((uint32_t)(c / cx.W) << 8);
-            OM content = direct_at(e, cx, xy);
-            if (content.count() > 1) {
-                int last = content.last();
+            for (int k = 0; k < OPL; ++k) {
+                bool on_static = (e.d0[k] & D_ALIVE) && (e.d1[k] & 0xFFu) == 0 && !((held.w[k] >> cx.lane) & 1);
+                if (on_static) e.d0[k] |= D_FREE;
+            }
+            CM boards;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) boards.w[k] = ballot((e.cell[k] & CELL_TYPE) == CUTBOARD);
+            while (boards.any()) {
+                int c = boards.first();
+                boards.clear(c);
+                uint32_t y = (uint32_t)c / (uint32_t)cx.W;
+                uint32_t xy = ((uint32_t)c - y * (uint32_t)cx.W) | (y << 8);
+                OM content = direct_at(e, xy);
+                if (content.count() > 1) {
+                    int last = content.last();
+#pragma unroll
+                    for (int k = 0; k < OPL; ++k)
+                        if (((content.w[k] >> cx.lane) & 1) && (cx.lane + 64 * k) != last) e.d0[k] &= ~D_FREE;
+                }
+            }
+            OM plates = oballot(e, [](uint32_t a, uint32_t) { return (a & (D_ALIVE | 0xFF0000u)) == (D_ALIVE | (PLATE << 16)); });
+            while (plates.any()) {
+                int p = plates.first();
+                plates.clear(p);
+                OM content = content_of(e, p);
+                int cnt = content.count();
+                if (cnt == 0) continue;
 #pragma unroll
                 for (int k = 0; k < OPL; ++k)
-                    if (((content.w[k] >> cx.lane) & 1) && (cx.lane + 64 * k) != last) e.d0[k] &= ~D_FREE;
+                    if ((content.w[k] >> cx.lane) & 1) {
+                        bool lastone = ((e.d1[k] >> 8) & 0xFFu) == (uint32_t)(cnt - 1);
+                        e.d0[k] = lastone ? (e.d0[k] | D_FREE) : (e.d0[k] & ~D_FREE);
+                    }
             }
         }
-        OM plates = oballot(e, [](uint32_t a, uint32_t) { return (a & D_ALIVE) && ((a >> 16) & 0xFF) == PLATE; });
-        while (plates.any()) {
-            int p = plates.first();
-            plates.clear(p);
-            OM content = content_of(e, p);
-            int cnt = content.count();
-            if (cnt == 0) continue;
-#pragma unroll
-            for (int k = 0; k < OPL; ++k)
-                if ((content.w[k] >> cx.lane) & 1) {
-                    bool lastone = ((e.d1[k] >> 8) & 0xFFu) == (uint32_t)(cnt - 1);
-                    e.d0[k] = lastone ? (e.d0[k] | D_FREE) : (e.d0[k] & ~D_FREE);
-                }
-        }
         // Switch.process_linked_objects world_objects.py:165-169 -> Block.switch_state :215-216 (all linked)
-        if (pressed) {
+        if (dt.pressed) {
 #pragma unroll
             for (int k = 0; k < CPL; ++k)
                 if ((e.cell[k] & CELL_TYPE) == BLOCK) e.cell[k] ^= CELL_WALK;
@@ -562,67 +592,77 @@ struct Ops {
     }
 
     // recipe.py:77-104 update_recipe_state for one recipe graph; returns the marks byte (bit j = node j marked).
-    // A node's matched set is kept as a bit set of CELLS, because the only thing a parent asks of a child's
-    // matches is location equality (recipe.py:103).
-    static __device__ __forceinline__ uint32_t recipe_marks(const E &e, const Ctx &cx, const uint32_t *__restrict__ rp) {
-        const int n = (int)rfl(rp[0]);
-        CM loc[MAX_NODES];
+    // A node's matched set is kept as a bit set of CELLS (in LDS scratch `locs`, MAX_NODES x CPL words), because the
+    // only thing a parent asks of a child's matches is location equality (recipe.py:103).  Children always follow
+    // their parent in node_list, so one pass from the last node to the first suffices.  Rolled on purpose: this is
+    // the cold path (it runs only on steps that changed an object) and must not bloat the hot path's registers.
+    // rowv: this lane's word of the recipe rows (lane rbase = node count, lane rbase+1+j = node j)
+    static __device__ __forceinline__ uint32_t recipe_marks(const E &e, const Ctx &cx, uint32_t rowv, int rbase,
+                                                            uint64_t *__restrict__ locs) {
+        const int n = (int)rdl(rowv, rbase);
         uint32_t marks = 0;
         uint32_t mycell[OPL];
 #pragma unroll
         for (int k = 0; k < OPL; ++k) mycell[k] = ((e.d0[k] >> 8) & 0xFFu) * (uint32_t)cx.W + (e.d0[k] & 0xFFu);
-#pragma unroll
-        for (int j = MAX_NODES - 1; j >= 0; --j) {
-            loc[j] = CM::zero();
-            if (j >= n) continue;
-            const uint32_t nd = rfl(rp[1 + j]);
+#pragma nounroll
+        for (int j = n - 1; j >= 0; --j) {
+            const uint32_t nd = rdl(rowv, rbase + 1 + j);
             const uint32_t cls = nd & 0xFF, cond = (nd >> 8) & 0xFF, children = (nd >> 16) & 0xFF;
             if ((marks & children) != children) continue;                 // all(contains.marked)
+            // intersection of the children's location sets
+            CM allow;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) allow.w[q] = ~0ull;
+            uint32_t ch = children;
+            while (ch) {
+                int c2 = __ffs((int)ch) - 1;
+                ch &= ch - 1;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    uint64_t w = locs[c2 * CPL + q];
+                    allow.w[q] &= ((uint64_t)rfl((uint32_t)(w >> 32)) << 32) | rfl((uint32_t)w);
+                }
+            }
+            CM here = CM::zero();
+            bool any = false;
             if (cls < 16) {                                               // a static class: candidates are cells
-                CM m;
 #pragma unroll
                 for (int k = 0; k < CPL; ++k)
-                    m.w[k] = ballot((e.cell[k] & CELL_TYPE) == cls && (cx.lane + 64 * k) < cx.W * cx.H);
-#pragma unroll
-                for (int c2 = 0; c2 < MAX_NODES; ++c2)
-                    if (c2 > j && (children >> c2) & 1) m = m & loc[c2];
-                loc[j] = m;
-                if (m.any()) marks |= 1u << j;
+                    here.w[k] = ballot((e.cell[k] & CELL_TYPE) == cls && (cx.lane + 64 * k) < cx.C) & allow.w[k];
+                any = here.any();
             } else if (cls < 32) {                                        // a dynamic class: candidates are slots
-                const uint32_t dc = cls - 16;
+                // class + condition as (word & cmask) == cval on the dyn0 word
+                uint32_t cmask = D_ALIVE | (0xFFu << 16), cval = D_ALIVE | ((cls - 16) << 16);
+                if (cond == COND_CHOPPED) { cmask |= D_CHOPPED; cval |= D_CHOPPED; }
+                else if (cond == COND_MASHED) { cmask |= D_MASHED; cval |= D_MASHED; }
+                else if (cond == COND_NOT_CHOPPED) cmask |= D_CHOPPED;
+                else if (cond == COND_NOT_MASHED) cmask |= D_MASHED;
                 OM m;
 #pragma unroll
                 for (int k = 0; k < OPL; ++k) {
-                    uint32_t a = e.d0[k];
-                    bool ok = (a & D_ALIVE) && ((a >> 16) & 0xFF) == dc;
-                    if (cond == COND_CHOPPED) ok = ok && (a & D_CHOPPED);
-                    else if (cond == COND_MASHED) ok = ok && (a & D_MASHED);
-                    else if (cond == COND_NOT_CHOPPED) ok = ok && !(a & D_CHOPPED);
-                    else if (cond == COND_NOT_MASHED) ok = ok && !(a & D_MASHED);
+                    uint64_t wsel = allow.w[0];
+                    if (CPL > 1) {
 #pragma unroll
-                    for (int c2 = 0; c2 < MAX_NODES; ++c2)
-                        if (c2 > j && (children >> c2) & 1) {
-                            uint64_t wsel = loc[c2].word((int)0);
-                            if (CPL > 1) {
-                                wsel = 0;
-#pragma unroll
-                                for (int q = 0; q < CPL; ++q)
-                                    if ((mycell[k] >> 6) == (uint32_t)q) wsel = loc[c2].w[q];
-                            }
-                            ok = ok && ((wsel >> (mycell[k] & 63)) & 1);
-                        }
-                    m.w[k] = ballot(ok);
-                }
-                if (m.any()) {
-                    marks |= 1u << j;
-                    // scatter matched objects to their cells (a handful of objects at most)
-                    OM it = m;
-                    while (it.any()) {
-                        int s = it.first();
-                        it.clear(s);
-                        uint32_t w = slot_d0(e, s);
-                        loc[j].set((int)(((w >> 8) & 0xFFu) * (uint32_t)cx.W + (w & 0xFFu)));
+                        for (int q = 1; q < CPL; ++q)
+                            if ((mycell[k] >> 6) == (uint32_t)q) wsel = allow.w[q];
                     }
+                    m.w[k] = ballot((e.d0[k] & cmask) == cval && ((wsel >> (mycell[k] & 63)) & 1));
+                }
+                any = m.any();
+                if (j > 0) {                                              // the root's locations are never consulted
+                    while (m.any()) {                                     // a handful of objects at most
+                        int s = m.first();
+                        m.clear(s);
+                        uint32_t w = slot_d0(e, s);
+                        here.set((int)(((w >> 8) & 0xFFu) * (uint32_t)cx.W + (w & 0xFFu)));
+                    }
+                }
+            }
+            if (any) {
+                marks |= 1u << j;
+                if (j > 0 && cx.lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) locs[j * CPL + q] = here.w[q];
                 }
             }
         }

@@ -17,6 +17,8 @@ Per-env *record* (array of little-endian u32 words, `record_words(cfg)` long):
                                      auto-reset (0 = whole pool); lets one batch mix levels
   word 7      reserved
   word 8..11  agents[4]              x | y<<8 | orientation<<16 | (held slot+1)<<24   world_objects.py:776-783
+  word 12..19 ret[4]                 float64 running return of the episode in flight, per agent slot
+                                     (cooking_env.py:265 _cumulative_rewards; device-side statistics only)
   then        cells[CW]              W*H bytes, 4 per word:  type | READY<<3 | TOGGLE<<4 | ACTIVE<<5 | WALK<<6
   then        dyn0[D]                x | y<<8 | cls<<16 | flags<<24
   then        dyn1[D]                (plate slot+1) | seq<<8     (ContentObject.content membership + position)
@@ -60,14 +62,35 @@ MAX_NODES = 8
 MAX_RECIPES_PER_ENV = 4
 MAX_AGENTS = 4
 
-# ---- observation descriptor ops (one u32 per feature: op | ref<<8)
-(OP_ZERO, OP_ONE, OP_CONST_X, OP_CONST_Y, OP_CELL_ACTIVE, OP_CELL_WALK, OP_DYN_X, OP_DYN_Y,
- OP_DYN_NOTDONE, OP_DYN_DONE, OP_DYN_CHOPPED, OP_DYN_MASHED, OP_DYN_ONE, OP_AG_X, OP_AG_Y,
- OP_AG_O1, OP_AG_O2, OP_AG_O3, OP_AG_O4, OP_AG_ONE) = range(20)
+# ---- observation descriptor: one u32 per feature =  (image halfword index * 2) | (axis code * 4) << 16
+# The kernel keeps, per env, an LDS "image" of halfwords; every halfword is a byte offset into a 256-entry table of
+# doubles (lut):  lut[i] = (i-(W-1))/W for i < 2W-1,  lut[64+i] = (i-(H-1))/H,  lut[126] = 0.0,  lut[127] = 1.0,
+# lut[128..255] = 0.0 (the "absent" zone: every halfword of a dead slot points at entry 255, and stays inside the
+# zone after an agent coordinate is subtracted).  Image layout (halfword indices):
+#   slot s    IMG_OBJ0 + 6 s : x+W-1 | y+64+H-1 | 126+!done | 126+chopped | 126+mashed | 127
+#   cell c    IMG_CELL0 + 4 c: x+W-1 | y+64+H-1 | 126+(switch_active or block walkable) | 127
+#   agent a   IMG_AG0 + 8 a  : x+W-1 | y+64+H-1 | 126+(o==1) | .. | 126+(o==4) | 127 | pad
+#   IMG_ZERO                 : 255
+# A feature value for observer a is  lut[image[hw] - sub[a][code]]  with the axis code choosing what is subtracted:
+#   0 nothing, 1 ax, 2 ay, 4+2j / 5+2j: ax / ay unless a == j (an agent's own position is absolute, cooking_env.py:366-368)
+IMG_OBJ0, IMG_CELL0, IMG_AG0, IMG_ZERO, IMG_HALFWORDS = 0, 768, 1792, 1824, 1826
+AX_NONE, AX_X, AX_Y = 0, 1, 2
+LUT_Y0, LUT_ZERO, LUT_ONE, LUT_ABSENT, LUT_SIZE = 64, 126, 127, 255, 256
+
+
+def desc_word(hw, code=0):
+    return ((hw * 2) & 0xFFFF) | ((code * 4) << 16)
+
+
+def ax_self(agent, axis):
+    """axis code of agent `agent`'s own x (axis 0) / y (axis 1) feature"""
+    return 4 + 2 * agent + axis
+
 
 HDR_WORDS = 8
 W_T, W_MARKS, W_LAYOUT, W_STATUS, W_EPISODE, W_RECIPES, W_POOL, W_RES1 = range(8)
 AGENT_WORD0 = HDR_WORDS
+RET_WORD0 = AGENT_WORD0 + 4          # 4 float64 = 8 words
 STATUS_DONE, STATUS_TERM, STATUS_TRUNC = 1, 2, 4
 
 
@@ -86,7 +109,7 @@ class Dims:
         self.W, self.H, self.D, self.A, self.F = int(width), int(height), int(max_dyn), int(num_agents), int(feat_len)
         self.C = self.W * self.H
         self.CW = (self.C + 3) // 4
-        self.cells_word0 = AGENT_WORD0 + MAX_AGENTS
+        self.cells_word0 = RET_WORD0 + 2 * MAX_AGENTS
         self.dyn0_word0 = self.cells_word0 + self.CW
         self.dyn1_word0 = self.dyn0_word0 + self.D
         used = self.dyn1_word0 + self.D

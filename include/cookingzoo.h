@@ -15,7 +15,7 @@
  * Per-env state travels as a flat "record" of cz_record_words() little-endian uint32 words:
  *   word 0 t | 1 recipe-node marks (bit 8r+j) | 2 layout id | 3 status (1 done, 2 terminated, 4 truncated)
  *   | 4 episode | 5 recipe ids (4 x u8) | 6 layout-pool slice (base | count<<16) | 7 reserved | 8..11 agents (x | y<<8 | orientation<<16 | (held slot+1)<<24)
- *   | cells (W*H bytes: type | READY<<3 | TOGGLE<<4 | ACTIVE<<5 | WALK<<6) | dyn0[D] (x | y<<8 | class<<16 | flags<<24;
+ *   | 12..19 four float64 running episode returns (statistics only) | cells (W*H bytes: type | READY<<3 | TOGGLE<<4 | ACTIVE<<5 | WALK<<6) | dyn0[D] (x | y<<8 | class<<16 | flags<<24;
  *   flags: 1 alive, 2 chopped, 4 mashed, 8 free) | dyn1[D] ((plate slot+1) | seq<<8), padded to 16 words.
  * (normative description: cooking_zoo_amd/soa.py)
  */
@@ -71,6 +71,7 @@ int32_t cz_record_words(cz_handle h);
 int32_t cz_abi_version(void);
 int32_t cz_sizeof_config(void);                           /* sizeof(cz_config), for binding self-checks */
 int32_t cz_sizeof_stats(void);
+int cz_debug_set_stamps(cz_handle h, void *d_buf);       /* diagnostic builds only (make prof): s_memtime stamp buffer */
 int cz_sync(cz_handle h);                                  /* wait for the handle's stream */
 
 /* ---- tables ---------------------------------------------------------------------------------------- */

@@ -85,7 +85,7 @@ typedef struct {
     int err;
 } World;
 
-static int cell_off(const czo_config *c) { return HDR_WORDS + CZO_MAX_AGENTS; }
+static int cell_off(const czo_config *c) { return HDR_WORDS + CZO_MAX_AGENTS + 2 * CZO_MAX_AGENTS; /* + running returns */ }
 static int dyn0_off(const czo_config *c) { return cell_off(c) + (c->width * c->height + 3) / 4; }
 static int dyn1_off(const czo_config *c) { return dyn0_off(c) + c->max_dyn; }
 

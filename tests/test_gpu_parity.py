@@ -21,6 +21,7 @@ def strip(rec):
     r[..., soa.W_LAYOUT] = 0
     r[..., soa.W_EPISODE] = 0
     r[..., soa.W_POOL] = 0
+    r[..., soa.RET_WORD0:soa.RET_WORD0 + 8] = 0        # running returns: device-side statistics only
     return r
 
 

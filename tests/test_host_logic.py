@@ -57,42 +57,40 @@ def test_layout_record_and_descriptor_match_reference(name):
 
 def eval_descriptor(desc, d, rec):
     """numpy restatement of the kernel's descriptor walk (host-side check of the table builder)."""
-    out = np.zeros((d.A, d.F))
+    lut = np.zeros(soa.LUT_SIZE)
+    for i in range(2 * d.W - 1):
+        lut[i] = (i - (d.W - 1)) / d.W
+    for i in range(2 * d.H - 1):
+        lut[soa.LUT_Y0 + i] = (i - (d.H - 1)) / d.H
+    lut[soa.LUT_ONE] = 1.0
+    img = np.full(soa.IMG_HALFWORDS, soa.LUT_ABSENT, dtype=np.int64)
     cells = soa.record_cells(d, rec)
     ag = [soa.unpack_agent(rec[soa.AGENT_WORD0 + a]) for a in range(d.A)]
+    for s_ in range(d.D):
+        x, y, c, fl = soa.unpack_dyn0(rec[d.dyn0_word0 + s_])
+        if fl & soa.DYN_ALIVE:
+            ch, ma = bool(fl & soa.DYN_CHOPPED), bool(fl & soa.DYN_MASHED)
+            img[soa.IMG_OBJ0 + 6 * s_:soa.IMG_OBJ0 + 6 * s_ + 6] = [x + d.W - 1, y + 64 + d.H - 1, 126 + (not (ch or ma)),
+                                                                  126 + ch, 126 + ma, 127]
+    for c in range(d.C):
+        f = bool(cells[c] & (soa.CELL_ACTIVE | soa.CELL_WALK))
+        img[soa.IMG_CELL0 + 4 * c:soa.IMG_CELL0 + 4 * c + 4] = [c % d.W + d.W - 1, c // d.W + 64 + d.H - 1, 126 + f, 127]
+    for a in range(d.A):
+        x, y, o, _ = ag[a]
+        img[soa.IMG_AG0 + 8 * a:soa.IMG_AG0 + 8 * a + 7] = [x + d.W - 1, y + 64 + d.H - 1] + [126 + (o == k) for k in (1, 2, 3, 4)] + [127]
+    out = np.zeros((d.A, d.F))
     for f, w in enumerate(desc):
-        op, ref = int(w) & 0xFF, int(w) >> 8
+        w = int(w)
+        hw, code = (w & 0xFFFF) // 2, (w >> 16) // 4
         for a in range(d.A):
-            ax, ay = ag[a][0], ag[a][1]
-            v = 0.0
-            if op == soa.OP_ONE:
-                v = 1.0
-            elif op == soa.OP_CONST_X:
-                v = (ref - ax) / d.W
-            elif op == soa.OP_CONST_Y:
-                v = (ref - ay) / d.H
-            elif op == soa.OP_CELL_ACTIVE:
-                v = float(bool(cells[ref] & soa.CELL_ACTIVE))
-            elif op == soa.OP_CELL_WALK:
-                v = float(bool(cells[ref] & soa.CELL_WALK))
-            elif soa.OP_DYN_X <= op <= soa.OP_DYN_ONE:
-                x, y, c, fl = soa.unpack_dyn0(rec[d.dyn0_word0 + ref])
-                if fl & soa.DYN_ALIVE:
-                    done = bool(fl & (soa.DYN_CHOPPED | soa.DYN_MASHED))
-                    v = {soa.OP_DYN_X: (x - ax) / d.W, soa.OP_DYN_Y: (y - ay) / d.H, soa.OP_DYN_NOTDONE: float(not done),
-                         soa.OP_DYN_DONE: float(done), soa.OP_DYN_CHOPPED: float(bool(fl & soa.DYN_CHOPPED)),
-                         soa.OP_DYN_MASHED: float(bool(fl & soa.DYN_MASHED)), soa.OP_DYN_ONE: 1.0}[op]
-            elif op >= soa.OP_AG_X:
-                gx, gy, go, _ = ag[ref]
-                if op == soa.OP_AG_X:
-                    v = gx / d.W if ref == a else (gx - ax) / d.W
-                elif op == soa.OP_AG_Y:
-                    v = gy / d.H if ref == a else (gy - ay) / d.H
-                elif op == soa.OP_AG_ONE:
-                    v = 1.0
-                else:
-                    v = float(go == op - soa.OP_AG_O1 + 1)
-            out[a, f] = v
+            sub = 0
+            if code == soa.AX_X:
+                sub = ag[a][0]
+            elif code == soa.AX_Y:
+                sub = ag[a][1]
+            elif code >= 4 and (code - 4) // 2 != a:
+                sub = ag[a][(code - 4) % 2]
+            out[a, f] = lut[img[hw] - sub]
     return out
 
 

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Where does a wave spend its cycles?  Needs the diagnostic build (make -C cooking_zoo_amd/csrc prof) and
+CZ_LIB=cooking_zoo_amd/csrc/libcookingzoo_hip_prof.so.  Prints median s_memtime deltas per phase (shares, not times)."""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+os.environ.setdefault("CZ_LIB", os.path.join(REPO, "cooking_zoo_amd", "csrc", "libcookingzoo_hip_prof.so"))
+from cooking_zoo_amd import _native  # noqa: E402
+from cooking_zoo_amd.vec_env import CookingVecEnv  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+env = CookingVecEnv(N, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3",
+                    num_layouts=256, auto_reset=True)
+env.reset(return_obs=False)
+L, h = _native.lib(), env._h
+stamps = env.alloc((N, 8), np.uint64)
+L.cz_debug_set_stamps(h, stamps.ptr)
+rng = np.random.default_rng(0)
+d_act = env.alloc((N, 2), np.int32)
+d_obs = env.alloc((N, 2, env.F), np.float64)
+d_rew = env.alloc((N, 2), np.float64)
+d_t = env.alloc((N, 2), np.uint8)
+d_u = env.alloc((N, 2), np.uint8)
+names = ["prologue+loads", "agents", "progress", "rewards/flags", "outputs", "observe", "store"]
+acc = []
+spread, endspread = [], []
+for it in range(60):
+    d_act.from_host(rng.integers(0, 5, size=(N, 2), dtype=np.int32))
+    env.step_device(d_act, d_obs, d_rew, d_t, d_u)
+    env.sync()
+    s = stamps.to_host().astype(np.int64)
+    if it >= 10:
+        acc.append(np.diff(s, axis=1))
+        spread.append(s[:, 0].max() - s[:, 0].min())
+        endspread.append(s[:, 7].max() - s[:, 0].min())
+d = np.concatenate(acc)
+tot = np.median((np.concatenate([a.sum(axis=1) for a in acc])))
+life = np.concatenate([a.sum(axis=1) for a in acc])
+print(f"wave lifetime cycles: median {tot:.0f}  p90 {np.percentile(life,90):.0f}  p99 {np.percentile(life,99):.0f}  max-per-launch median {np.median([a.sum(axis=1).max() for a in acc]):.0f}")
+st = np.concatenate([ (a[:,0]*0) for a in acc])
+print("per-launch: first-start -> last-start", np.median(spread), "cycles; first-start -> last-end", np.median(endspread), "cycles")
+for i, n in enumerate(names):
+    print(f"  {n:16s} median {np.median(d[:, i]):8.0f}  mean {d[:, i].mean():8.0f}  ({100 * d[:, i].mean() / d.sum(axis=1).mean():4.1f} %)")
+
+slow = d[life > np.percentile(life, 99)]
+print("slowest 1% of waves: mean cycles per phase")
+for i, n in enumerate(names):
+    print(f"  {n:16s} {slow[:, i].mean():8.0f}")
