@@ -1,0 +1,223 @@
+"""Drop-in `parallel_env` for the step() path, backed by the HIP kernels (one env instance on one wavefront).
+
+Same constructor kwargs, method names, dict keys and return shapes as the reference's
+`cooking_zoo.environment.cooking_env.parallel_env` (cooking_env.py:26-46, 62-64, 178-210, 243-269, 271-288):
+
+    env = parallel_env(level=..., meta_file=..., num_agents=..., max_steps=..., recipes=[...],
+                       obs_spaces=["feature_vector", ...], action_scheme="scheme3", reward_scheme=None, ...)
+    obs, infos = env.reset()
+    obs, rewards, terminations, truncations, infos = env.step({"player_0": a0, "player_1": a1})
+
+What is deliberately not offered ("out of scope" / "next"): the "symbolic" and "full" observation modes,
+pygame rendering, agent despawn/respawn rates > 0 and scheme2 (which raises AttributeError in the reference itself).
+For many envs at once use cooking_zoo_amd.vec_env.CookingVecEnv -- this facade is the num_envs = 1 case of it.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+
+from cooking_zoo_amd import soa, spaces
+from cooking_zoo_amd.cooking_book import recipe_drawer
+from cooking_zoo_amd.cooking_world.actions import ACTION_SCHEMES
+from cooking_zoo_amd.cooking_world.engine import load_level as _ll
+from cooking_zoo_amd.vec_env import CookingVecEnv
+
+FPS = 20
+COLORS = ['blue', 'magenta', 'yellow', 'green']
+
+
+class WorldView:
+    """Read-only snapshot of the world for callers that peek at `env.unwrapped.world` (demos do)."""
+
+    def __init__(self, dims, record):
+        self.width, self.height = dims.W, dims.H
+        self.agents = []
+        for a in range(dims.A):
+            x, y, o, h = soa.unpack_agent(record[soa.AGENT_WORD0 + a])
+            self.agents.append({"location": (x, y), "orientation": o, "holding_slot": h, "name": f"agent-{a + 1}",
+                                "color": COLORS[a]})
+        self.cells = soa.record_cells(dims, record).reshape(dims.H, dims.W).copy()
+        self.dynamic_objects = []
+        for s in range(dims.D):
+            x, y, c, f = soa.unpack_dyn0(record[dims.dyn0_word0 + s])
+            cont, seq = soa.unpack_dyn1(record[dims.dyn1_word0 + s])
+            if f & soa.DYN_ALIVE:
+                self.dynamic_objects.append({"class": soa.DYNAMIC_CLASSES[c], "location": (x, y), "slot": s,
+                                             "chopped": bool(f & soa.DYN_CHOPPED), "mashed": bool(f & soa.DYN_MASHED),
+                                             "free": bool(f & soa.DYN_FREE), "inside_plate_slot": cont})
+
+
+class CookingEnvironment:
+    """Parallel (dict-in / dict-out) CookingZoo environment; what `parallel_env(...)` returns."""
+
+    metadata = {"render_modes": ["human", "rgb_array"], "name": "cookingzoo_v1", "is_parallelizable": True,
+                "render_fps": FPS}
+
+    def __init__(self, level, meta_file, num_agents, max_steps, recipes, agent_visualization=None, obs_spaces=None,
+                 end_condition_all_dishes=False, allowed_objects=None, action_scheme="scheme1", render=False,
+                 reward_scheme=None, agent_respawn_rate=0.0, grace_period=20, agent_despawn_rate=0.0, device_id=0):
+        obs_spaces = obs_spaces or ["feature_vector"]
+        allowed = ["symbolic", "full", "feature_vector"]
+        assert len(set(obs_spaces + allowed)) == 3, f"Selected invalid obs spaces. Allowed {allowed}"
+        if any(o != "feature_vector" for o in obs_spaces[:num_agents]):
+            raise NotImplementedError("only the 'feature_vector' observation is produced on the device "
+                                      "('symbolic' deep-copies Python objects, 'full' is constant zeros upstream)")
+        if action_scheme == "scheme2":
+            raise AttributeError("'CookingWorld' object has no attribute 'perform_agent_action' (scheme2 is unusable in "
+                                 "the reference: action_scheme2.py:15)")
+        if agent_respawn_rate or agent_despawn_rate:
+            raise NotImplementedError("agent despawn/respawn (rates > 0) is not part of the accelerated path yet")
+        self.level, self.meta_file, self.max_steps = level, meta_file, max_steps
+        self.action_scheme = action_scheme
+        self.action_scheme_class = ACTION_SCHEMES[action_scheme]
+        self.obs_spaces = obs_spaces
+        self.possible_agents = ["player_" + str(r) for r in range(num_agents)]
+        self.agents = self.possible_agents[:]
+        self.agent_visualization = agent_visualization or ["human"] * num_agents
+        self.reward_scheme = reward_scheme or {"recipe_reward": 20, "max_time_penalty": -5, "recipe_penalty": -40,
+                                               "recipe_node_reward": 0}
+        self.recipe_names = list(recipes)
+        self.end_condition_all_dishes = end_condition_all_dishes
+        self.render_flag = render
+        self.termination_info = ""
+        self.t = 0
+
+        meta = _ll.load_meta_file(meta_file)
+        assert num_agents <= meta["Agent"], "Too many agents for this level"
+        level_object = _ll.load_level_file(level)
+        # the reference's constructor loads the level once (cooking_env.py:109): same draws from `random`
+        first = _ll.instantiate(level_object, meta, num_agents, random)
+        self._vec = CookingVecEnv(1, level, meta_file, num_agents, max_steps, recipes,
+                                  end_condition_all_dishes=end_condition_all_dishes, action_scheme=action_scheme,
+                                  reward_scheme=self.reward_scheme, layouts=[first], auto_reset=False,
+                                  device_id=device_id, max_dyn=max(_ll.level_max_dyn(level_object), 1))
+        self._level_object, self._meta = level_object, meta
+        self._cached_layout = first
+        self.num_goals = recipe_drawer.NUM_GOALS if recipe_drawer.RECIPE_STORE else recipe_drawer.DEFAULT_NUM_GOALS
+        self.recipe_graphs = [self._vec.book[r]() for r in recipes]
+        self.loaded_recipes = list(self._vec.book.keys())
+        # goal vectors are indexed by agent position, not by recipe (reference defect kept: cooking_env.py:159-161)
+        eye = np.eye(len(self.loaded_recipes))
+        self.goal_vectors = {a: eye[i] for i, a in zip(range(len(self.loaded_recipes)), self.possible_agents)}
+        F = self._vec.F
+        self.feature_vector_representation_length = F
+        self.feature_obs_space = spaces.Box(low=-1, high=1, shape=(F,))
+        self.observation_spaces = {a: self.feature_obs_space for a in self.possible_agents}
+        self.action_spaces = {a: spaces.Discrete(len(self.action_scheme_class.ACTIONS)) for a in self.possible_agents}
+        self.rewards = {a: 0 for a in self.agents}
+        self.terminations = {a: False for a in self.agents}
+        self.truncations = {a: False for a in self.agents}
+        self.infos = {a: {} for a in self.agents}
+        self._needs_reset = True
+        self.render_mode = "human"
+        self.np_random = None
+
+    # ------------------------------------------------------------------ PettingZoo parallel API
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def num_agents(self):
+        return len(self.agents)
+
+    @property
+    def max_num_agents(self):
+        return len(self.possible_agents)
+
+    def observation_space(self, agent):
+        return self.observation_spaces[agent]
+
+    def action_space(self, agent):
+        return self.action_spaces[agent]
+
+    def state(self):
+        return None
+
+    def seed(self, seed=None):
+        self.np_random = np.random.default_rng(seed)
+
+    def reset(self, seed=None, return_info=False, options=None):
+        """cooking_env.py:178-210.  `seed` is ignored, as in the reference (level draws come from Python's global
+        `random`); options={"full_reset": False} re-uses the most recently drawn layout."""
+        options = options or {"full_reset": True}
+        self.t = 0
+        self.termination_info = ""
+        self.agents = self.possible_agents[:]
+        if options["full_reset"]:
+            self._cached_layout = _ll.instantiate(self._level_object, self._meta, len(self.possible_agents), random)
+            self._vec.set_layouts([self._cached_layout])
+        obs = self._vec.reset(layout_ids=[0])
+        self._refresh_marks()
+        self.rewards = {a: 0 for a in self.agents}
+        self.terminations = {a: False for a in self.agents}
+        self.truncations = {a: False for a in self.agents}
+        self.infos = {a: {} for a in self.agents}
+        self._needs_reset = False
+        return {a: obs[0, i].copy() for i, a in enumerate(self.agents)}, dict(self.infos)
+
+    def step(self, actions):
+        """One accumulated_step (cooking_env.py:243-269) + observe for every agent (cooking_env.py:271-288)."""
+        if self._needs_reset or not self.agents:
+            raise RuntimeError("the episode is over (or reset() was never called): call reset() before step()")
+        acts = [int(actions[a]) for a in self.possible_agents]
+        n = self.action_spaces[self.possible_agents[0]].n
+        if any(a < 0 or a >= n for a in acts):
+            raise ValueError(f"actions must be in [0, {n}) for {self.action_scheme}")
+        obs, rew, term, trunc = self._vec.step(np.asarray([acts], dtype=np.int32))
+        self.t += 1
+        self._refresh_marks()
+        truncated = bool(trunc[0, 0])
+        if truncated:
+            self.termination_info = f"Terminating because {self.max_steps} timesteps passed"
+        info = {"t": self.t, "termination_info": self.termination_info}
+        self.rewards, self.terminations, self.truncations, self.infos = {}, {}, {}, {}
+        observations = {}
+        for i, a in enumerate(self.possible_agents):
+            observations[a] = obs[0, i].copy()
+            self.rewards[a] = np.float64(rew[0, i])
+            self.terminations[a] = bool(term[0, i])
+            self.truncations[a] = bool(trunc[0, i])
+            self.infos[a] = {"goal_vector": self.goal_vectors[a], **info,
+                             "recipe_done": self.recipe_graphs[i].completed(), "action": acts[i],
+                             "task": self.recipe_names[i]}
+        if truncated or bool(term[0, 0]):
+            # the reference empties the agent list after the final step (truncation: cooking_env.py:336-339,267-268;
+            # termination: its wrapper loop cannot make progress, SURVEY A.12(5) -- the build ends the episode cleanly)
+            self.agents = []
+            self._needs_reset = True
+        return observations, dict(self.rewards), dict(self.terminations), dict(self.truncations), dict(self.infos)
+
+    def observe(self, agent):
+        return self._vec.observe()[0, self.possible_agents.index(agent)].copy()
+
+    def _refresh_marks(self):
+        marks = int(self._vec.get_state()[0, soa.W_MARKS])
+        for r, g in enumerate(self.recipe_graphs):
+            g.set_marks((marks >> (8 * r)) & 0xFF)
+
+    @property
+    def world(self):
+        return WorldView(self._vec.dims, self._vec.get_state()[0])
+
+    def render(self, **kwargs):
+        raise NotImplementedError("rendering (pygame GraphicPipeline) is outside the accelerated step path")
+
+    def close(self):
+        self._vec.close()
+
+
+def env(**kwargs):
+    """The reference's `env()` returns the AEC environment; the accelerated path only offers the parallel API."""
+    raise NotImplementedError("the AEC (agent-iterator) API is not offered; use parallel_env(...)")
+
+
+def parallel_env(level, meta_file, num_agents, max_steps, recipes, agent_visualization=None, obs_spaces=None,
+                 end_condition_all_dishes=False, action_scheme="scheme1", render=False, reward_scheme=None,
+                 agent_respawn_rate=0.0, grace_period=20, agent_despawn_rate=0.0, device_id=0):
+    return CookingEnvironment(level, meta_file, num_agents, max_steps, recipes, agent_visualization, obs_spaces,
+                              end_condition_all_dishes=end_condition_all_dishes, action_scheme=action_scheme,
+                              render=render, reward_scheme=reward_scheme, agent_respawn_rate=agent_respawn_rate,
+                              grace_period=grace_period, agent_despawn_rate=agent_despawn_rate, device_id=device_id)

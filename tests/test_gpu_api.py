@@ -1,0 +1,79 @@
+"""GPU: the drop-in surface (parallel_env / gym-style wrappers) against wrapper-level traces captured from the reference."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+TRACES = json.load(open(os.path.join(HERE, "golden", "api_traces.json")))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.mark.parametrize("case", TRACES, ids=lambda c: f"{c['kwargs']['level']}-A{c['kwargs']['num_agents']}-{c['kwargs']['action_scheme']}")
+def test_parallel_env_matches_reference_trace(case):
+    from cooking_zoo_amd.environment.cooking_env import parallel_env
+    random.seed(case["seed"])
+    np.random.seed(case["seed"])
+    env = parallel_env(**case["kwargs"])
+    assert env.possible_agents == case["possible_agents"]
+    assert list(env.observation_space("player_0").shape) == case["obs_shape"]
+    assert env.action_space("player_0").n == case["n_actions"]
+    obs, infos = env.reset()
+    assert infos == {a: {} for a in env.possible_agents}
+    for a, o in case["reset_obs"].items():
+        assert obs[a].dtype == np.float64 and np.array_equal(bits(obs[a]), bits(np.array(o)))
+    for st in case["steps"]:
+        o, r, te, tr, inf = env.step({f"player_{i}": a for i, a in enumerate(st["actions"])})
+        assert set(o) == set(st["obs"])
+        for a in st["obs"]:
+            assert np.array_equal(bits(o[a]), bits(np.array(st["obs"][a]))), a
+            assert isinstance(r[a], np.float64) and np.array_equal(bits(r[a]), bits(np.array(st["rewards"][a])))
+            assert te[a] == st["terminations"][a] and tr[a] == st["truncations"][a]
+            ref_info = st["infos"][a]
+            assert set(inf[a]) == set(ref_info)
+            assert inf[a]["t"] == ref_info["t"] and inf[a]["termination_info"] == ref_info["termination_info"]
+            assert inf[a]["recipe_done"] == ref_info["recipe_done"] and inf[a]["action"] == ref_info["action"]
+            assert inf[a]["task"] == ref_info["task"] and list(inf[a]["goal_vector"]) == ref_info["goal_vector"]
+        assert env.agents == st["agents_after"]
+    if not env.agents:
+        with pytest.raises(RuntimeError):
+            env.step({a: 0 for a in env.possible_agents})
+    env.close()
+
+
+def test_full_reset_false_reuses_layout_and_gym_wrappers():
+    from cooking_zoo_amd.environment import GymCookingEnvironment, GymCookingEnvironmentMA
+    random.seed(3)
+    g = GymCookingEnvironment("coop_test", "example", 20, ["TomatoLettuceSalad"], action_scheme="scheme3")
+    o1, i1 = g.reset()
+    assert o1.shape == (278,) and i1 == {}
+    first = g.zoo_env.world.cells.copy()
+    g.zoo_env.reset(options={"full_reset": False})
+    assert np.array_equal(g.zoo_env.world.cells, first)
+    o, r, te, tr, info = g.step(0)
+    assert o.shape == (278,) and r == -5 / 20 and te is False and tr is False and info["t"] == 1
+    g.close()
+    m = GymCookingEnvironmentMA("coop_test", "example", 2, 3, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3")
+    obs, infos = m.reset()
+    assert len(obs) == 2 and len(infos) == 2
+    for t in range(3):
+        obs, rew, te, tr, inf = m.step([1, 2])
+    assert tr == [True, True] and m.zoo_env.agents == []
+    m.close()
+
+
+def test_unsupported_modes_fail_loudly():
+    from cooking_zoo_amd.environment.cooking_env import parallel_env
+    kw = dict(level="coop_test", meta_file="example", num_agents=1, max_steps=10, recipes=["TomatoSalad"])
+    with pytest.raises(NotImplementedError):
+        parallel_env(obs_spaces=["symbolic"], action_scheme="scheme3", **kw)
+    with pytest.raises(AttributeError):
+        parallel_env(action_scheme="scheme2", **kw)
+    with pytest.raises(NotImplementedError):
+        parallel_env(action_scheme="scheme3", agent_despawn_rate=0.1, **kw)

@@ -571,10 +571,97 @@ def main():
                      max_steps=200, meta=metac),
             [(130, "uniform", 200), (131, "bumper", 200)], args.out)
 
+    sets["api_traces"] = lambda: api_traces(args.out)
+    sets["layouts_ref"] = lambda: layout_draws(args.out)
     for name, fn in sets.items():
         if args.only and args.only != name:
             continue
         fn()
+
+
+
+
+# ------------------------------------------------------------------------------------------------
+# wrapper-level API traces (parallel_env dict-in / dict-out) and level-instantiation layouts
+# ------------------------------------------------------------------------------------------------
+
+def api_traces(out_dir):
+    """(kwargs, seed, actions) -> the five dicts of every parallel_env.step, incl. a termination and a truncation.
+    The parallel wrapper is tools/refshim's paraphrase of pettingzoo's (plumbing only)."""
+    cases = [
+        dict(seed=1, kwargs=dict(level="coop_test", meta_file="example", num_agents=1, max_steps=400,
+                                 recipes=["TomatoLettuceSalad"], obs_spaces=["feature_vector"],
+                                 end_condition_all_dishes=True, action_scheme="scheme3"),
+             actions=[[int(c)] for c in "312442214141113331242131124444"]),
+        dict(seed=7, kwargs=dict(level="coop_test", meta_file="example", num_agents=2, max_steps=5,
+                                 recipes=["TomatoLettuceSalad", "CarrotBanana"], obs_spaces=["feature_vector", "feature_vector"],
+                                 action_scheme="scheme3"),
+             actions=[[1, 2], [3, 4], [0, 1], [2, 2], [4, 3]]),
+        dict(seed=11, kwargs=dict(level="switch_test", meta_file="example", num_agents=2, max_steps=30,
+                                  recipes=["TomatoSalad", "MashedCarrotBanana"], obs_spaces=["feature_vector", "feature_vector"],
+                                  action_scheme="scheme1",
+                                  reward_scheme={"recipe_reward": 10, "max_time_penalty": -3, "recipe_penalty": -7,
+                                                 "recipe_node_reward": 1}),
+             actions=[[int(a), int(b)] for a, b in np.random.default_rng(5).integers(0, 8, size=(30, 2))]),
+    ]
+    out = []
+    for case in cases:
+        random.seed(case["seed"])
+        np.random.seed(case["seed"])
+        env = parallel_env(**case["kwargs"])
+        obs, infos = env.reset()
+        rec = {"seed": case["seed"], "kwargs": case["kwargs"], "possible_agents": list(env.possible_agents),
+               "reset_obs": {k: v.tolist() for k, v in obs.items()}, "reset_infos": {k: dict(v) for k, v in infos.items()},
+               "obs_shape": list(env.observation_space("player_0").shape), "n_actions": int(env.action_space("player_0").n),
+               "steps": []}
+        for acts in case["actions"]:
+            if not env.agents:
+                break
+            ad = {f"player_{i}": a for i, a in enumerate(acts)}
+            o, r, te, tr, inf = env.step(ad)
+            rec["steps"].append({
+                "actions": acts, "obs": {k: v.tolist() for k, v in o.items()},
+                "rewards": {k: float(v) for k, v in r.items()}, "terminations": {k: bool(v) for k, v in te.items()},
+                "truncations": {k: bool(v) for k, v in tr.items()},
+                "infos": {k: {kk: (vv.tolist() if hasattr(vv, "tolist") else vv) for kk, vv in v.items()} for k, v in inf.items()},
+                "agents_after": list(env.agents)})
+        out.append(rec)
+    path = os.path.join(out_dir, "api_traces.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print(f"[golden] api_traces: {len(out)} cases, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def layout_draws(out_dir):
+    """random.seed(s) -> the layouts the reference instantiates (two consecutive draws), for the host loader test."""
+    from cooking_zoo.cooking_world.cooking_world import CookingWorld
+    from cooking_zoo.cooking_world.actions import ActionScheme3
+    L = os.path.join(REPO, "cooking_zoo_amd", "utils", "level")
+    M = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files")
+    cases = [("coop_test", "example", 2), ("coop_test", "example", 1), ("coexistence_test", "example", 2),
+             ("switch_test", "example", 2), (os.path.join(L, "large_16x16.json"), os.path.join(M, "large_16x16.json"), 4),
+             (os.path.join(L, "crowded_6x5.json"), os.path.join(M, "crowded_6x5.json"), 3)]
+    out = []
+    for level, meta, A in cases:
+        for seed in (0, 1, 2, 3, 12345):
+            random.seed(seed)
+            draws = []
+            for _ in range(2):
+                w = CookingWorld(ActionScheme3, meta)
+                w.load_level(level, A)
+                statics = {k: [[o.location[0], o.location[1]] for o in v] for k, v in w.world_objects.items()
+                           if issubclass(wo.StringToClass[k], StaticObject)}
+                dyn = [[k, [[o.location[0], o.location[1]] for o in v]] for k, v in w.world_objects.items()
+                       if issubclass(wo.StringToClass[k], DynamicObject) and v]
+                draws.append({"width": w.width, "height": w.height, "statics": statics, "dynamics": dyn,
+                              "agents": [[a.location[0], a.location[1]] for a in w.agents]})
+            out.append({"level": os.path.splitext(os.path.basename(level))[0],
+                        "meta": os.path.splitext(os.path.basename(meta))[0], "num_agents": A, "seed": seed, "draws": draws,
+                        "next_random": random.random()})
+    path = os.path.join(out_dir, "layouts_ref.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print(f"[golden] layouts_ref: {len(out)} cases, {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 if __name__ == "__main__":
