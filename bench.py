@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the CookingZoo step() hot path on MI355X (BASELINE.json metric).
 
-A "step" is one batched env step (one cz_step_device launch) over every env of the rank: world dynamics,
-recipe checks, rewards and the float64 feature-vector encode of all agents, with actions and outputs resident
-in HBM.  Workload at N GPUs = BASELINE config 2 per GPU (weak scaling): 4096 envs, level coop_test, 2 agents,
-recipes [TomatoLettuceSalad, CarrotBanana], scheme3, max_steps 400, a pool of 256 layouts, next-step
-auto-reset.  Prints ONE JSON line on rank 0.
+A "step" is one batched env step (one `cz_step_device` launch) over every env of the rank: world dynamics, recipe
+checks, rewards and the float64 feature-vector encode of all agents, with actions and outputs resident in HBM.
+Workload at N GPUs = BASELINE config 2 per GPU (weak scaling): 4096 envs, level coop_test, 2 agents, recipes
+[TomatoLettuceSalad, CarrotBanana], scheme3, max_steps 400, a pool of 256 layouts, next-step auto-reset, uniform
+random actions.  Prints ONE JSON line on rank 0.
 
     python bench.py --gpus 1 --steps 2000 --warmup 200
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -23,57 +24,71 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
 def algorithmic_bytes_per_env_step(env):
     """SURVEY.md 8(d):  A(8F + 8 + 1 + 1) written + 4A actions read + 2*S_dyn + W*H static cells read,
-    S_dyn = 4A + 4D + action objects + linked + 4 (t) + ceil(nodes/8).  For cfg 2 this is 4655 B."""
-    A, F, D = env.num_agents, env.F, 12 if env.dims.D <= 12 else env.dims.D
-    lay = env.layouts[0]
-    n_action = len(lay.static_lists.get("Cutboard", [])) + len(lay.static_lists.get("Blender", []))
-    n_action = max(n_action, 4) if env.dims.C == 49 else n_action
-    n_linked = len(lay.static_lists.get("Switch", [])) + len(lay.static_lists.get("Block", []))
+    S_dyn = 4A + 4D + action objects + linked + 4 (t) + ceil(nodes/8).  4655 B for config 2 (D = 12: 10 objects + 2
+    Bread clones, 4 action objects: 3 Cutboards + 1 Blender, 8 recipe nodes)."""
+    A, F, C = env.num_agents, env.F, env.dims.C
+    D = max(l.slots_used for l in env.layouts)
+    n_action = max(len(l.static_lists.get("Cutboard", [])) + len(l.static_lists.get("Blender", [])) for l in env.layouts)
+    n_linked = max(len(l.static_lists.get("Switch", [])) + len(l.static_lists.get("Block", [])) for l in env.layouts)
     nodes = sum(int(env.recipe_table[r][0]) for r in env.recipe_ids[0][:env.num_recipes])
     s_dyn = 4 * A + 4 * D + n_action + n_linked + 4 + (nodes + 7) // 8
-    return A * (8 * F + 10) + 4 * A + 2 * s_dyn + env.dims.C
+    return A * (8 * F + 10) + 4 * A + 2 * s_dyn + C
 
 
-def cpu_baseline(env, seconds_target=12.0):
-    """The oracle (a bit-exact C port of the reference step path, oracle/cz_oracle.c) timed on this box's host
-    cores on a bounded sample of the same workload: per thread a disjoint slice of envs, 400-step episodes with
-    the same counter-based action stream, observations encoded every step."""
+def cpu_baseline(env, seconds_target=15.0):
+    """The oracle (a bit-exact C port of the reference step path, oracle/cz_oracle.c) timed on this box's host cores
+    on a bounded sample of the same workload: every thread steps its own slice of envs through 400-step episodes with
+    the same counter-based action stream and encodes the observations every step."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from oracle_binding import VecOracle
     cores = len(os.sched_getaffinity(0))
     envs_per_thread, T = 8, 400
-    # calibrate on one thread
-    vo = VecOracle.from_vec_env(env, num_envs=envs_per_thread)
-    vo.reset()
-    t0 = time.perf_counter()
-    vo.rollout(T, 0)
-    one = envs_per_thread * T / (time.perf_counter() - t0)
-    reps = max(1, int(seconds_target * one / (envs_per_thread * T)))
-    reps = min(reps, 64)
     workers = [VecOracle.from_vec_env(env, num_envs=envs_per_thread, env_id_base=i * envs_per_thread) for i in range(cores)]
     for w in workers:
         w.reset()
 
-    def run(w):
-        for r in range(reps):
-            w.rollout(T, 0, r * T)
+    def run_all(reps, first):
+        def run(w):
+            for r in range(reps):
+                w.rollout(T, 0, (first + r) * T)
+        ths = [threading.Thread(target=run, args=(w,)) for w in workers]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        return time.perf_counter() - t0
 
-    ths = [threading.Thread(target=run, args=(w,)) for w in workers]
     t0 = time.perf_counter()
-    for th in ths:
-        th.start()
-    for th in ths:
-        th.join()
-    dt = time.perf_counter() - t0
+    workers[0].rollout(T, 0, 0)
+    single = envs_per_thread * T / (time.perf_counter() - t0)
+    dt1 = run_all(1, 1)                                        # calibration pass on all cores
+    reps = int(min(max(seconds_target / max(dt1, 1e-3), 1), 2000))
+    dt = run_all(reps, 2)
     total = cores * envs_per_thread * T * reps
     return {"value": total / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} threads x {envs_per_thread} envs x {T * reps} steps of the bench workload "
-                      f"({total} env-steps, {dt:.1f} s; single-thread rate {one:.0f} env-steps/s)"}
+            "sample": f"oracle/cz_oracle.c, {cores} threads x {envs_per_thread} envs x {T * reps} steps of the bench "
+                      f"workload incl. obs encode ({total} env-steps in {dt:.1f} s); one thread alone: {single:.0f} env-steps/s"}
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/rNN/traffic.json), or None."""
+    best = None
+    for d in sorted(os.listdir(os.path.join(REPO, "profiles"))) if os.path.isdir(os.path.join(REPO, "profiles")) else []:
+        p = os.path.join(REPO, "profiles", d, "traffic.json")
+        if os.path.exists(p):
+            try:
+                t = json.load(open(p))
+                if kernel_key in t:
+                    best = t[kernel_key]
+            except Exception:
+                pass
+    return best
 
 
 def main():
@@ -89,65 +104,63 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
+    dist = torch = None
     if world > 1:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from cooking_zoo_amd import _native
+    from cooking_zoo_amd import _native, distributed as czd
     from cooking_zoo_amd.vec_env import CookingVecEnv
 
     N = args.envs
     K, Wm = args.steps, args.warmup
-    env = CookingVecEnv(N, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"],
+    begin, count = czd.shard_range(N * world, world, rank)
+    env = CookingVecEnv(count, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"],
                         action_scheme="scheme3", num_layouts=256, layout_seed=0, auto_reset=True,
-                        device_id=local_rank, env_id_base=rank * N)
+                        device_id=local_rank, env_id_base=begin)
     L, h = _native.lib(), env._h
     env.reset(return_obs=False)
 
-    # inputs resident in HBM: one int32 [N, A] action tensor per step (uniform over the 5 scheme3 actions,
-    # counter-based stream keyed by the global env id), outputs: obs f64 [N, A, F], rewards, flags
+    # inputs resident in HBM: one int32 [N, A] action tensor per step (uniform over the 5 scheme3 actions);
+    # outputs: obs f64 [N, A, F], rewards f64, terminations / truncations u8
     chunk = 256
-    acts = np.empty((chunk, N, 2), dtype=np.int32)
-    e_ids = (rank * N + np.arange(N)).astype(np.int64)
     rng = np.random.default_rng(1234 + rank)
-    acts[:] = rng.integers(0, 5, size=acts.shape, dtype=np.int32)
     d_actions = env.alloc((chunk, N, 2), np.int32)
-    d_actions.from_host(acts)
+    d_actions.from_host(rng.integers(0, 5, size=(chunk, N, 2), dtype=np.int32))
     d_obs = env.alloc((N, 2, env.F), np.float64)
     d_rew = env.alloc((N, 2), np.float64)
     d_term = env.alloc((N, 2), np.uint8)
     d_trunc = env.alloc((N, 2), np.uint8)
     step_bytes = N * 2 * 4
+    obs_ptr = None if args.no_obs else d_obs.ptr
 
     def run_steps(k, first):
         for t in range(first, first + k):
-            rc = L.cz_step_device(h, d_actions.ptr + (t % chunk) * step_bytes, None if args.no_obs else d_obs.ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr)
+            rc = L.cz_step_device(h, d_actions.ptr + (t % chunk) * step_bytes, obs_ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr)
             if rc:
                 _native.check(h, rc)
 
     def barrier():
         env.sync()
         if dist is not None:
-            import torch
             torch.cuda.synchronize()
             dist.barrier()
 
     run_steps(Wm, 0)
     barrier()
     s0 = env.stats()["env_steps"]
+    L.cz_timer_start(h)                                        # HIP event on the stream the kernels run on
     t0 = time.perf_counter()
     run_steps(K, Wm)
+    ev_ms = C.c_float()
+    L.cz_timer_stop(h, C.byref(ev_ms))                         # HIP event after the K-th launch, synchronised
     barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    s1 = env.stats()["env_steps"]
-    local_env_steps = s1 - s0            # world steps actually executed (reset passes are not counted)
+    elapsed = time.perf_counter() - t0
+    local_env_steps = env.stats()["env_steps"] - s0            # world steps executed (auto-reset passes are not counted)
 
     if dist is not None:
-        import torch
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -157,33 +170,48 @@ def main():
     else:
         total_env_steps = local_env_steps
 
-    # dominant-kernel duration, measured live with HIP events on the stream the kernel runs on
-    L.cz_kernel_time_reset(h, 1)
-    kl = min(K, 500)
-    run_steps(kl, Wm + K)
-    import ctypes as C
-    ms, nl = C.c_double(), C.c_int64()
-    L.cz_kernel_time_read(h, C.byref(ms), C.byref(nl))
-    L.cz_kernel_time_reset(h, 0)
-    kernel_us = ms.value * 1e3 / max(1, nl.value)
+    # dominant-kernel duration: HIP events bracket the timed region on the kernels' own stream; the K launches run
+    # back to back (rocprofv3 --kernel-trace shows no gaps, profiles/), so duration = event time / K
+    kernel_us = ev_ms.value * 1e3 / K
+
+    # secondary figure: the same work fused, T steps per launch with the on-device action stream and a trajectory buffer
+    fused = None
+    if not args.no_obs:
+        T = 32
+        d_traj = env.alloc((T, N, 2, env.F), np.float64)
+        d_r = env.alloc((T, N, 2), np.float64)
+        d_te = env.alloc((T, N, 2), np.uint8)
+        d_tr = env.alloc((T, N, 2), np.uint8)
+        reps = max(2, K // T)
+        env.rollout(T, 1, 0, d_traj, d_r, d_te, d_tr)
+        barrier()
+        f0 = env.stats()["env_steps"]
+        t0 = time.perf_counter()
+        for r in range(reps):
+            env.rollout(T, 1, (r + 1) * T, d_traj, d_r, d_te, d_tr)
+        barrier()
+        dtf = time.perf_counter() - t0
+        fused = {"env_steps_per_s_per_gpu": (env.stats()["env_steps"] - f0) / dtf, "steps_per_launch": T,
+                 "ms_per_step": dtf * 1e3 / (reps * T), "api": "cz_rollout, obs trajectory [T][N][A][F] in HBM"}
+        for b in (d_traj, d_r, d_te, d_tr):
+            b.free()
 
     # episode statistics: RCCL all-gather over xGMI of one cz_stats per rank (the path's only collective)
     stats_all = None
     if dist is not None:
         try:
-            import torch
-            uid = (C.c_uint8 * 128)()
-            if rank == 0:
-                _native.check(None, L.cz_comm_unique_id(uid))
-            box = [bytes(uid)]
-            dist.broadcast_object_list(box, src=0)
-            uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
-            _native.check(h, L.cz_comm_init(h, world, rank, uid))
-            out = (_native.CzStats * world)()
-            _native.check(h, L.cz_stats_allgather(h, out))
-            stats_all = [out[i].as_dict() for i in range(world)]
-        except Exception as exc:                      # keep the timing result even if the stats exchange fails
-            stats_all = {"error": str(exc)}
+            def bcast(payload):
+                box = [payload]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            per_rank = czd.gather_stats_rccl(env, world, rank, bcast)
+            stats_all = {"via": "rccl (cz_stats_allgather)", "total": czd.reduce_stats(per_rank)}
+        except Exception as exc:
+            try:
+                per_rank = czd.gather_stats_torch(env.stats(), device=torch.device("cuda", local_rank))
+                stats_all = {"via": f"torch.distributed nccl (direct RCCL path failed: {exc})", "total": czd.reduce_stats(per_rank)}
+            except Exception as exc2:            # keep the timing result even if the stats exchange fails
+                stats_all = {"error": f"{exc}; {exc2}"}
 
     if rank == 0:
         b_alg = algorithmic_bytes_per_env_step(env)
@@ -196,15 +224,18 @@ def main():
             "dtype": "u8/u32 state, f64 obs+reward", "data": "synthetic",
             "config": {"workload": f"{N} envs per GPU x {world} GPU(s), level=coop_test, 2 agents, "
                                    f"recipes=[TomatoLettuceSalad, CarrotBanana], scheme3, max_steps=400, "
-                                   f"256-layout pool, on-device auto-reset, feature_vector obs F={env.F} f64",
+                                   f"256-layout pool, on-device auto-reset, feature_vector obs F={env.F} f64, "
+                                   f"uniform random actions",
                        "envs_per_gpu": N, "parallelism": f"env-sharded x{world}, one wavefront per env",
-                       "api": "cz_step_device, one launch per step, actions/obs/rewards resident in HBM"},
+                       "api": "cz_step_device: one launch per step, actions/obs/rewards/flags resident in HBM"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_step<1,1>", "kernel_us": kernel_us, "alg_bytes_per_env_step": b_alg,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(f"k_step_{N}"),
+                         "kernel": "k_step<1,1,2,3,false>", "kernel_us": kernel_us, "alg_bytes_per_env_step": b_alg,
                          "units_per_launch": N},
             "achieved_hbm_gbs_end_to_end": b_alg * value / 1e9 / world,
         }
+        if fused is not None:
+            line["fused_rollout"] = fused
         if stats_all is not None:
             line["episode_stats_allgather"] = stats_all
         if world == 1 and not args.no_cpu_baseline:
