@@ -1,0 +1,31 @@
+#!/bin/bash
+# GPU box: rocprofv3 evidence for bench.py's workload.  usage: bash tools/collect_profiles.sh TAG
+# (kernel trace + stats in one run; FETCH_SIZE and WRITE_SIZE in separate --pmc passes, as the microarch guide prescribes)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+TAG=${1:-cur}
+O=gpurun_out/prof_$TAG
+mkdir -p $O/trace $O/fetch $O/write $O/insts
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline > $O/bench_under_trace.json 2> $O/trace.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAVES --output-format csv -d $O/insts -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
+python3 bench.py > $O/bench.json 2> $O/bench.err
+python3 tools/trace_gaps.py $O/trace > $O/trace_gaps.txt
+python3 - <<PY
+import csv, glob, json, collections
+O="$O"
+def pmc(d, pat):
+    agg=collections.defaultdict(list)
+    for f in glob.glob(d+"/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if pat in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k:(sum(v)/len(v), len(v)) for k,v in agg.items()}
+out={}
+for pat,key in (("3, false>", "step"), ("3, true>", "fused")):
+    f=pmc(O+"/fetch", pat); w=pmc(O+"/write", pat); i=pmc(O+"/insts", pat)
+    out[key]={"FETCH_SIZE_KB_per_launch": f.get("FETCH_SIZE",(None,0))[0], "WRITE_SIZE_KB_per_launch": w.get("WRITE_SIZE",(None,0))[0],
+              "insts": {k:v[0] for k,v in i.items()}, "dispatches": {"fetch": f.get("FETCH_SIZE",(0,0))[1], "write": w.get("WRITE_SIZE",(0,0))[1]}}
+json.dump(out, open(O+"/pmc_summary.json","w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
+cat $O/trace_gaps.txt; find $O/trace -name "*kernel_stats.csv" -exec cat {} \; | cut -c1-220
