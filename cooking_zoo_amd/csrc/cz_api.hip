@@ -174,6 +174,8 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     P.recipe_reward = cfg->recipe_reward; P.recipe_penalty = cfg->recipe_penalty; P.node_reward = cfg->recipe_node_reward;
     P.time_penalty_step = cfg->max_time_penalty / (double)cfg->max_steps;       // cooking_env.py:307
     P.T = 1;
+    P.stop = -1;
+    if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // honoured by the diagnostic build only
     h->kl = (P.D <= 64 && C <= 64) ? launchers_small() : launchers_large();
     {   // the reward of a step on which no recipe node changed: cooking_env.py:304-307 with zero deltas, same op order
         double x = 0.0;
@@ -247,7 +249,17 @@ extern "C" int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n) {
     if (h->d_recipes) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->d_recipes)); }
     size_t bytes = (size_t)n * (1 + MAX_NODES) * 4;
     HIPCHK(h, hipMalloc(&h->d_recipes, bytes));
-    HIPCHK(h, hipMemcpyAsync(h->d_recipes, table, bytes, hipMemcpyHostToDevice, h->stream));
+    // device copy: word 0 of every row additionally carries, in bits 8.., the mask of dynamic classes its nodes name
+    std::vector<uint32_t> dev(table, table + (size_t)n * (1 + MAX_NODES));
+    for (int i = 0; i < n; ++i) {
+        uint32_t *row = dev.data() + (size_t)i * (1 + MAX_NODES), mask = 0;
+        for (uint32_t j = 0; j < row[0]; ++j) {
+            uint32_t cls = row[1 + j] & 0xFF;
+            if (cls >= 16 && cls < 32) mask |= 1u << (cls - 16);
+        }
+        row[0] = (row[0] & 0xFFu) | (mask << 8);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_recipes, dev.data(), bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->n_recipes = n;
     h->P.recipes = h->d_recipes;
@@ -291,7 +303,8 @@ extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const 
     }
     size_t b0 = (size_t)n * h->P.RW * 4, b1 = (size_t)n * h->P.F * 4;
     HIPCHK(h, hipMalloc(&h->d_lay_init, b0));
-    HIPCHK(h, hipMalloc(&h->d_lay_desc, b1));
+    HIPCHK(h, hipMalloc(&h->d_lay_desc, b1 + 16));                 // + padding: descriptors are fetched in pairs
+    HIPCHK(h, hipMemsetAsync(h->d_lay_desc, 0, b1 + 16, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_lay_init, init_records, b0, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_lay_desc, obs_desc, b1, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -69,6 +69,7 @@ struct Params {
     int32_t dyn0_off, dyn1_off;    // word offsets inside a record
     int32_t walk_touches;          // 1 if carrying an object across cells can change a recipe mark (see cz_load_recipes)
     unsigned long long *stamps;    // diagnostic build only: [N][8] s_memtime stamps (nullptr in the shipped library)
+    int32_t stop;                  // diagnostic build only: phase index after which the kernel returns (CZ_STOP), else -1
 };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -167,7 +168,7 @@ template <int OPL, int CPL, int NA>
 struct Env {
     uint32_t d0[OPL], d1[OPL];     // per lane: slots lane + 64k
     uint32_t cell[CPL];            // per lane: cells lane + 64k
-    int ax[NA], ay[NA], ao[NA], ah[NA];                                   // uniform; ah = held slot or -1
+    uint32_t agw;                  // lane a < NA: agent a as x | y<<8 | orientation<<16 | (held slot+1)<<24 (record word 8+a)
     uint32_t t, marks, layout, status, episode, recipes, pool;            // uniform header
 };
 
@@ -181,6 +182,7 @@ struct Dirty {                     // what this step changed (uniform)
     uint32_t interacted;           // containment / free flags may have changed  -> free-flag normalisation needed
     uint32_t cells;                // some mutable cell bit changed              -> the cell bytes must be written back
     uint32_t moved;                // a held object was carried to another cell  -> objects must be written back
+    uint32_t classes;              // bit c: an object of dynamic class c moved or changed state (recipe filter); ~0 = any
 };
 
 template <int NA>
@@ -286,6 +288,13 @@ struct Ops {
     // One agent's view while it acts (uniform scalars, written back by the caller)
     struct Me { int x, y, o, h; };
 
+    // record that the object with dyn0 word `w` moved or changed state; a plate drags its content along -> any class
+    static __device__ __forceinline__ void touch(Dirty &dt, uint32_t w) {
+        const uint32_t cls = (w >> 16) & 0xFFu;
+        dt.touched = 1;
+        dt.classes |= (cls == PLATE) ? 0xFFFFFFFFu : (1u << cls);
+    }
+
     // cooking_world.py:243-261 attempt_merge (first matching branch only, no fall-through on refusal).
     // dyn = objects at the target cell, sv = its cell byte, (lx, ly) the cell
     static __device__ __forceinline__ void attempt_merge(E &e, const Ctx &cx, Me &me, const OM &dyn, int lx, int ly, int c,
@@ -304,7 +313,7 @@ struct Ops {
                 plate_add(e, cx, p, held, cnt);
                 move_obj(e, cx, held, lxy);                      // Agent.put_down world_objects.py:789-791
                 me.h = -1;
-                dt.touched = 1;
+                touch(dt, hw);
             }
         } else if (hcls == PLATE && dyn.any()) {
             int o = dyn.last();                                   // pick_index = -1
@@ -313,7 +322,7 @@ struct Ops {
             if ((ow & 0xFF0000u) != (PLATE << 16) && (ow & D_DONE) && cnt < 64) {
                 plate_add(e, cx, held, o, cnt);
                 move_obj(e, cx, o, (uint32_t)me.x | ((uint32_t)me.y << 8));
-                dt.touched = 1;
+                touch(dt, ow);
                 // static_object.content.remove(o) is implicit: o now carries a container tag
             }
         } else {
@@ -333,7 +342,7 @@ struct Ops {
                 slot_or(e, cx, held, D_FREE);
                 move_obj(e, cx, held, lxy);
                 me.h = -1;
-                dt.touched = 1;
+                touch(dt, hw);
             }
         }
     }
@@ -361,8 +370,8 @@ struct Ops {
                 int grab = fr.any() ? fr.first() : dyn.last();
                 if (direct.test(grab)) {                        // object_to_grab in static_object.content
                     me.h = grab;                                // Agent.grab world_objects.py:785-787
+                    touch(dt, slot_d0(e, grab));
                     move_obj(e, cx, grab, (uint32_t)me.x | ((uint32_t)me.y << 8));
-                    dt.touched = 1;
                 }
             }
         } else {
@@ -387,8 +396,8 @@ struct Ops {
         for (int k = 0; k < OPL; ++k)
             if (cx.lane + 64 * k == s) e.d1[k] = 0;        // content.pop(-1)
         me.h = s;
+        touch(dt, slot_d0(e, s));
         move_obj(e, cx, s, (uint32_t)me.x | ((uint32_t)me.y << 8));
-        dt.touched = 1;
         dt.interacted = 1;
     }
 
@@ -416,79 +425,84 @@ struct Ops {
                     }
             }
             cell_update(e, cx, c, CELL_READY, 0, dt);
-            dt.touched = 1;
+            touch(dt, fw);
             dt.interacted = 1;
         } else if (ty == BLENDER) {
             if (sv & CELL_READY) cell_update(e, cx, c, 0, CELL_TOGGLE, dt);
         }
     }
 
+    // gather the byte of cell `c` (per-lane index) from the lanes that own the cells
+    static __device__ __forceinline__ uint32_t cell_gather(const E &e, uint32_t c) {
+        if (CPL == 1) return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)e.cell[0]);
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((c & 63u) << 2), (int)e.cell[k]);
+            if ((c >> 6) == (uint32_t)k) v = t;
+        }
+        return v;
+    }
+
     // action_scheme3.py:4-43 / action_scheme1.py:4-40 perform_agent_actions (+ check_inbounds
-    // cooking_world.py:192-204, check_collisions :206-221)
-    static __device__ __forceinline__ void perform_agent_actions(E &e, const Ctx &cx, const int (&raw)[NA], Dirty &dt) {
-        int act[NA], tx[NA], ty[NA], tcv[NA];        // cleaned action, its target cell and that cell's byte
-        int ex[NA], ey[NA];
-        bool wk[NA];
+    // cooking_world.py:192-204, check_collisions :206-221).  `act` : lane a = raw action of agent a.
+    // The pre-pass and both filters run for all agents at once (lane a = agent a); the execution loop is serial
+    // in agent order (action_scheme3.py:15-16) and pulls one agent out of the vectors with v_readlane.
+    static __device__ __forceinline__ void perform_agent_actions(E &e, const Ctx &cx, uint32_t act, Dirty &dt) {
+        const uint32_t W = (uint32_t)cx.W, H = (uint32_t)cx.H;
+        uint32_t x = e.agw & 0xFFu, y = (e.agw >> 8) & 0xFFu, o = (e.agw >> 16) & 0xFFu;
+        act &= 7u;
+        if (act - 1u < 4u) o = act;                                         // change_orientation before any filtering
+        uint32_t tx = x + ((DX_TABLE >> (2u * act)) & 3u) - 1u, ty = y + ((DY_TABLE >> (2u * act)) & 3u) - 1u;
+        // check_inbounds (0 and 5 pass; 6 and 7 aim at the own cell, always inside); negative wraps to huge
+        if (tx >= W || ty >= H) { act = 0; tx = x; ty = y; }
+        const uint32_t own = y * W + x;
+        uint32_t c = ty * W + tx;
+        const uint32_t ocv = cell_gather(e, own);
+        uint32_t tcv = cell_gather(e, c);
+        const bool wk = walkable(tcv);
+        // check_collisions: an agent is cancelled iff its end cell equals another agent's end cell and its own
+        // target was walkable.  count how many agents (including itself) end on this lane's end cell
+        const uint32_t exy = wk ? (tx | (ty << 8)) : (x | (y << 8));
+        uint32_t cnt = 0;
 #pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            int r = raw[a];
-            if ((uint32_t)(r - 1) < 4u) e.ao[a] = r;                    // change_orientation before any filtering
-            int x = e.ax[a] + (int)((DX_TABLE >> (2 * r)) & 3u) - 1;
-            int y = e.ay[a] + (int)((DY_TABLE >> (2 * r)) & 3u) - 1;
-            // check_inbounds (0 and 5 pass; 6 and 7 aim at the own cell, always inside)
-            if ((uint32_t)x >= (uint32_t)cx.W || (uint32_t)y >= (uint32_t)cx.H) { r = 0; x = e.ax[a]; y = e.ay[a]; }
-            act[a] = r; tx[a] = x; ty[a] = y;
-            tcv[a] = (int)cell_at(e, y * cx.W + x);
-            wk[a] = walkable((uint32_t)tcv[a]);
-            ex[a] = wk[a] ? x : e.ax[a];
-            ey[a] = wk[a] ? y : e.ay[a];
-        }
-        if (NA > 1) {
-#pragma unroll
-            for (int a = 0; a < NA; ++a) {
-                bool clash = false;
-#pragma unroll
-                for (int b = 0; b < NA; ++b)
-                    if (b != a && ex[b] == ex[a] && ey[b] == ey[a]) clash = true;
-                if (clash && wk[a] && act[a] != 0) {                    // cancelled: the agent now "walks" onto its own cell
-                    act[a] = 0; tx[a] = e.ax[a]; ty[a] = e.ay[a];
-                    tcv[a] = (int)cell_at(e, ty[a] * cx.W + tx[a]);
-                }
-            }
-        }
+        for (int b = 0; b < NA; ++b) cnt += (exy == rdl(exy, b)) ? 1u : 0u;
+        if (NA > 1 && cnt > 1u && wk && act != 0u) { act = 0; tx = x; ty = y; c = own; tcv = ocv; }   // now "walks" onto its own cell
+        if (cx.lane < NA) e.agw = (e.agw & 0xFF00FFFFu) | (o << 16);          // lanes >= NA stay 0 (unused agent words)
+        const uint32_t aux0 = act | (tcv << 8) | (c << 16);
+        const uint32_t aux1 = tx | (ty << 8);
 #pragma nounroll
         for (int a = 0; a < NA; ++a) {
-            const int ac = sel<NA>(act, a);
-            const int lx = sel<NA>(tx, a), ly = sel<NA>(ty, a);
-            const int c = ly * cx.W + lx;
-            Me me{sel<NA>(e.ax, a), sel<NA>(e.ay, a), sel<NA>(e.ao, a), sel<NA>(e.ah, a)};
-            // cell types and Block walkability cannot change before the end of the step, so the byte read in the
+            const uint32_t A = rdl(e.agw, a), X0 = rdl(aux0, a), lxy = rdl(aux1, a);
+            const int ac = (int)(X0 & 0xFFu);
+            const uint32_t cv0 = (X0 >> 8) & 0xFFu;
+            const int cc = (int)(X0 >> 16);
+            Me me{(int)(A & 0xFFu), (int)((A >> 8) & 0xFFu), (int)((A >> 16) & 0xFFu), (int)(A >> 24) - 1};
+            // cell types and Block walkability cannot change before the end of the step, so the byte gathered in the
             // pre-pass still decides "walkable"; READY / TOGGLE bits may have been changed by an earlier agent
-            const uint32_t cv0 = (uint32_t)sel<NA>(tcv, a);
             const bool is_walk = SCHEME == 3 || (uint32_t)(ac - 1) < 4u;
             if (is_walk && walkable(cv0)) {
                 // action_scheme3.py:26-34 resolve_walking_action (scheme3: also for action 0, re-pressing a Switch)
                 if (me.h >= 0 && ac != 0) {                             // Agent.move_to world_objects.py:793-796
-                    move_obj(e, cx, me.h, (uint32_t)lx | ((uint32_t)ly << 8));
+                    move_obj(e, cx, me.h, lxy);
                     dt.moved = 1;
                 }
-                me.x = lx; me.y = ly;
+                me.x = (int)(lxy & 0xFFu); me.y = (int)(lxy >> 8);
                 if ((cv0 & CELL_TYPE) == SWITCH) {                      // Switch.add_content :159-163
-                    cell_update(e, cx, c, 0, CELL_ACTIVE, dt);
+                    cell_update(e, cx, cc, 0, CELL_ACTIVE, dt);
                     dt.pressed = 1;
                 }
             } else if (SCHEME == 3 ? ac != 0 : ac >= 5) {
                 // the cell in front (scheme3: the bumped cell; scheme1: by orientation, may be off-grid)
-                int fx = lx, fy = ly, fc = c;
-                uint32_t sv;
+                int fx = (int)(lxy & 0xFFu), fy = (int)(lxy >> 8), fc = cc;
                 bool ok = true;
                 if (SCHEME != 3) {
                     fx = me.x + (int)((DX_TABLE >> (2 * me.o)) & 3u) - 1;
                     fy = me.y + (int)((DY_TABLE >> (2 * me.o)) & 3u) - 1;
-                    ok = (uint32_t)fx < (uint32_t)cx.W && (uint32_t)fy < (uint32_t)cx.H;   // reference: IndexError; build: no-op
+                    ok = (uint32_t)fx < W && (uint32_t)fy < H;          // reference: IndexError; build: no-op
                     fc = fy * cx.W + fx;
                 }
-                sv = ok ? cell_at(e, fc) : 0u;
+                const uint32_t sv = ok ? cell_at(e, fc) : 0u;
                 if (ok && holds_objects(sv & CELL_TYPE)) {
                     const uint32_t fxy = (uint32_t)fx | ((uint32_t)fy << 8);
                     // get_objects_at(location, DynamicObject) cooking_world.py:232-241 as a slot mask
@@ -507,9 +521,8 @@ struct Ops {
                     }
                 }
             }
-            put<NA>(e.ax, a, me.x);
-            put<NA>(e.ay, a, me.y);
-            put<NA>(e.ah, a, me.h);
+            const uint32_t newA = (uint32_t)me.x | ((uint32_t)me.y << 8) | ((uint32_t)me.o << 16) | ((uint32_t)((me.h + 1) & 0xFF) << 24);
+            e.agw = wrl(newA, a, e.agw);
         }
     }
 
@@ -534,6 +547,7 @@ struct Ops {
                 OM mashed = content & oballot(e, [](uint32_t a, uint32_t) { return (a & D_MASHED) != 0; });
                 if (mashed.count() == content.count()) cell_update(e, cx, c, CELL_READY | CELL_TOGGLE, 0, dt);
                 dt.touched = 1;
+                dt.classes |= (1u << CARROT) | (1u << BANANA);          // the only BlenderFood classes
                 dt.interacted = 1;
             }
         }
@@ -545,36 +559,48 @@ struct Ops {
         if (dt.interacted) {
             OM held = OM::zero();
 #pragma unroll
-            for (int a = 0; a < NA; ++a)
-                if (e.ah[a] >= 0) held.set(e.ah[a]);
+            for (int a = 0; a < NA; ++a) {
+                const int hs = (int)(rdl(e.agw, a) >> 24) - 1;
+                if (hs >= 0) held.set(hs);
+            }
+            // every object lying directly on a static is the last (only) item of that static's content ...
 #pragma unroll
             for (int k = 0; k < OPL; ++k) {
                 bool on_static = (e.d0[k] & D_ALIVE) && (e.d1[k] & 0xFFu) == 0 && !((held.w[k] >> cx.lane) & 1);
                 if (on_static) e.d0[k] |= D_FREE;
             }
-            CM boards;
+            // ... except on a Cutboard that carries a Bread and its clone (the only way a static gets two items,
+            // world_objects.py:738-745): both are chopped Breads lying directly on the same cell
+            OM twins = oballot(e, [](uint32_t a, uint32_t b) {
+                return (a & (D_ALIVE | D_CHOPPED | 0xFF0000u)) == (D_ALIVE | D_CHOPPED | (BREAD << 16)) && (b & 0xFFu) == 0;
+            }).andnot(held);
+            if (twins.count() > 1) {
+                OM it = twins;
+                while (it.any()) {
+                    const int s = it.first();
+                    const uint32_t xy = slot_d0(e, s) & 0xFFFFu;
+                    OM content = direct_at(e, xy).andnot(held);
+                    it = it.andnot(content);
+                    if (content.count() > 1) {
+                        const int last = content.last();
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) boards.w[k] = ballot((e.cell[k] & CELL_TYPE) == CUTBOARD);
-            while (boards.any()) {
-                int c = boards.first();
-                boards.clear(c);
-                uint32_t y = (uint32_t)c / (uint32_t)cx.W;
-                uint32_t xy = ((uint32_t)c - y * (uint32_t)cx.W) | (y << 8);
-                OM content = direct_at(e, xy);
-                if (content.count() > 1) {
-                    int last = content.last();
-#pragma unroll
-                    for (int k = 0; k < OPL; ++k)
-                        if (((content.w[k] >> cx.lane) & 1) && (cx.lane + 64 * k) != last) e.d0[k] &= ~D_FREE;
+                        for (int k = 0; k < OPL; ++k)
+                            if (((content.w[k] >> cx.lane) & 1) && (cx.lane + 64 * k) != last) e.d0[k] &= ~D_FREE;
+                    }
                 }
             }
-            OM plates = oballot(e, [](uint32_t a, uint32_t) { return (a & (D_ALIVE | 0xFF0000u)) == (D_ALIVE | (PLATE << 16)); });
-            while (plates.any()) {
-                int p = plates.first();
-                plates.clear(p);
+            // inside a plate: free iff last appended
+            OM inside = oballot(e, [](uint32_t a, uint32_t b) { return (a & D_ALIVE) && (b & 0xFFu) != 0; });
+            while (inside.any()) {
+                const int s = inside.first();
+                uint32_t b1 = 0;
+#pragma unroll
+                for (int k = 0; k < OPL; ++k)
+                    if (OPL == 1 || (s >> 6) == k) b1 = rdl(e.d1[k], s & 63);
+                const int p = (int)(b1 & 0xFFu) - 1;
                 OM content = content_of(e, p);
-                int cnt = content.count();
-                if (cnt == 0) continue;
+                inside = inside.andnot(content);
+                const int cnt = content.count();
 #pragma unroll
                 for (int k = 0; k < OPL; ++k)
                     if ((content.w[k] >> cx.lane) & 1) {
@@ -599,7 +625,7 @@ struct Ops {
     // rowv: this lane's word of the recipe rows (lane rbase = node count, lane rbase+1+j = node j)
     static __device__ __forceinline__ uint32_t recipe_marks(const E &e, const Ctx &cx, uint32_t rowv, int rbase,
                                                             uint64_t *__restrict__ locs) {
-        const int n = (int)rdl(rowv, rbase);
+        const int n = (int)(rdl(rowv, rbase) & 0xFFu);
         uint32_t marks = 0;
         uint32_t mycell[OPL];
 #pragma unroll

@@ -15,6 +15,9 @@ namespace cz {
         __builtin_amdgcn_sched_barrier(0);                                                             \
         if (lane == 0 && P.stamps) P.stamps[(size_t)env * 8 + (i)] = _t;                               \
     } while (0)
+#elif defined(CZ_ABLATE)
+// instruction-count ablation build (make ablate): CZ_STOP=i truncates the step after phase i; no stamps, no asm
+#define CZ_STAMP(i) do { if (P.stop == (i)) return; } while (0)
 #else
 #define CZ_STAMP(i) do { } while (0)
 #endif
@@ -31,38 +34,57 @@ struct Lds {
     uint64_t locs[MAX_NODES * 4];  // recipe evaluation scratch: matched-location bit sets per node (CPL <= 4 words)
 };
 
+// Memory access helpers: a wave-uniform base pointer plus a 32-bit unsigned per-lane byte offset, which the backend
+// turns into the `global_load/store v, v_off, s[base:base+1]` form (no 64-bit per-lane address arithmetic).
+template <class T>
+__device__ __forceinline__ T ldg(const void *sbase, uint32_t voff) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(sbase) + voff);
+}
+template <class T>
+__device__ __forceinline__ void stg(void *sbase, uint32_t voff, T v) {
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(sbase) + voff) = v;
+}
+// write-through store (`global_store ... sc1`): the bytes leave the XCD's L2 right away instead of staying dirty until
+// the end-of-kernel write-back, which would otherwise serialise ~B / 6 TB/s behind the kernel (MI355X_MICROARCH.md,
+// "boundary" and "publish-large" rows).  Used for the streaming outputs (observations), which nobody re-reads on the GPU.
+template <class T>
+__device__ __forceinline__ void stg_wt(void *sbase, uint32_t voff, T v) {
+    __hip_atomic_store(reinterpret_cast<T *>(reinterpret_cast<char *>(sbase) + voff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
+
 // Loads are clamped instead of exec-masked (no branches): every address stays inside the record.
 template <int OPL, int CPL, int NA>
 __device__ __forceinline__ void load_env(const Params &P, Env<OPL, CPL, NA> &e, const Ctx &cx, const uint32_t *__restrict__ rec) {
-    const uint32_t h = rec[cx.lane & 15];                                  // header + agents (record is >= 32 words)
-    const uint8_t *cb = reinterpret_cast<const uint8_t *>(rec + CELL_WORD0);
+    const uint32_t lane = (uint32_t)cx.lane;
+    const uint32_t h = ldg<uint32_t>(rec, (lane & 7u) * 4u);                         // header words
+    const uint32_t aw = ldg<uint32_t>(rec, (AGENT_WORD0 + (lane & 3u)) * 4u);        // agent words, lane a = agent a
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
-        int c = cx.lane + 64 * k;
-        uint32_t v = cb[min(c, cx.C - 1)];
-        e.cell[k] = (c < cx.C) ? v : 0u;
+        const uint32_t c = lane + 64u * k;
+        const uint32_t v = ldg<uint8_t>(rec, CELL_WORD0 * 4u + min(c, (uint32_t)cx.C - 1u));
+        e.cell[k] = (c < (uint32_t)cx.C) ? v : 0u;
     }
 #pragma unroll
     for (int k = 0; k < OPL; ++k) {
-        int s = cx.lane + 64 * k, sc = min(s, cx.D - 1);
-        uint32_t a = rec[P.dyn0_off + sc], b = rec[P.dyn1_off + sc];
-        e.d0[k] = (s < cx.D) ? a : 0u;
-        e.d1[k] = (s < cx.D) ? b : 0u;
+        const uint32_t s = lane + 64u * k, sc = min(s, (uint32_t)cx.D - 1u);
+        const uint32_t a = ldg<uint32_t>(rec, ((uint32_t)P.dyn0_off + sc) * 4u), b = ldg<uint32_t>(rec, ((uint32_t)P.dyn1_off + sc) * 4u);
+        e.d0[k] = (s < (uint32_t)cx.D) ? a : 0u;
+        e.d1[k] = (s < (uint32_t)cx.D) ? b : 0u;
     }
     e.t = rdl(h, W_T); e.marks = rdl(h, W_MARKS); e.layout = rdl(h, W_LAYOUT); e.status = rdl(h, W_STATUS);
     e.episode = rdl(h, W_EPISODE); e.recipes = rdl(h, W_RECIPES); e.pool = rdl(h, W_POOL);
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-        uint32_t w = rdl(h, AGENT_WORD0 + a);
-        e.ax[a] = (int)(w & 0xFF); e.ay[a] = (int)((w >> 8) & 0xFF); e.ao[a] = (int)((w >> 16) & 0xFF);
-        e.ah[a] = (int)(w >> 24) - 1;
-    }
+    e.agw = (lane < (uint32_t)NA) ? aw : 0u;
 }
 
-// header + agents in one 16-lane store (v_writelane assembles the words), cells / objects only when they changed
+// header + agents in one 12-lane store (v_writelane assembles the words), cells / objects only when they changed
 template <int OPL, int CPL, int NA>
 __device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t *__restrict__ rec,
                                           bool cells_dirty, bool objs_dirty) {
+    const uint32_t lane = (uint32_t)cx.lane;
     uint32_t h = 0;
     h = wrl(e.t, W_T, h);
     h = wrl(e.marks, W_MARKS, h);
@@ -71,26 +93,22 @@ __device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL, N
     h = wrl(e.episode, W_EPISODE, h);
     h = wrl(e.recipes, W_RECIPES, h);
     h = wrl(e.pool, W_POOL, h);
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-        h = wrl((uint32_t)e.ax[a] | ((uint32_t)e.ay[a] << 8) | ((uint32_t)e.ao[a] << 16) |
-                                           ((uint32_t)((e.ah[a] + 1) & 0xFF) << 24), AGENT_WORD0 + a, h);
-    if (cx.lane < RET_WORD0) rec[cx.lane] = h;
+    if (lane < (uint32_t)HDR_WORDS) stg<uint32_t>(rec, lane * 4u, h);
+    if (lane < (uint32_t)MAX_AGENTS) stg<uint32_t>(rec, (AGENT_WORD0 + lane) * 4u, e.agw);
     if (cells_dirty) {
-        uint8_t *cb = reinterpret_cast<uint8_t *>(rec + CELL_WORD0);
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
-            int c = cx.lane + 64 * k;
-            if (c < cx.C) cb[c] = (uint8_t)e.cell[k];
+            const uint32_t c = lane + 64u * k;
+            if (c < (uint32_t)cx.C) stg<uint8_t>(rec, CELL_WORD0 * 4u + c, (uint8_t)e.cell[k]);
         }
     }
     if (objs_dirty) {
 #pragma unroll
         for (int k = 0; k < OPL; ++k) {
-            int s = cx.lane + 64 * k;
-            if (s < cx.D) {
-                rec[P.dyn0_off + s] = e.d0[k];
-                rec[P.dyn1_off + s] = e.d1[k];
+            const uint32_t s = lane + 64u * k;
+            if (s < (uint32_t)cx.D) {
+                stg<uint32_t>(rec, ((uint32_t)P.dyn0_off + s) * 4u, e.d0[k]);
+                stg<uint32_t>(rec, ((uint32_t)P.dyn1_off + s) * 4u, e.d1[k]);
             }
         }
     }
@@ -98,9 +116,10 @@ __device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL, N
 
 // the recipe rows of this env, one word per lane: lane 9r + i = word i of the row of recipe r
 __device__ __forceinline__ uint32_t load_recipe_rows(const Params &P, uint32_t recipes, int lane) {
-    const int r = lane / 9, i = lane - 9 * r;
-    const uint32_t id = (recipes >> (8 * (r & 3))) & 0xFFu;
-    return (r < P.R) ? P.recipes[(size_t)id * (1 + MAX_NODES) + i] : 0u;
+    const uint32_t l = min((uint32_t)lane, 9u * (uint32_t)P.R - 1u);          // lanes past the rows re-read the last word
+    const uint32_t r = (l * 57u) >> 9, i = l - 9u * r;                         // l / 9 for l < 64
+    const uint32_t id = (recipes >> (8u * r)) & 0xFFu;
+    return ldg<uint32_t>(P.recipes, (id * (1u + MAX_NODES) + i) * 4u);
 }
 
 template <int OPL, int CPL, int NA>
@@ -115,8 +134,8 @@ __device__ __forceinline__ uint32_t all_marks(const Params &P, const Env<OPL, CP
 template <int CPL>
 __device__ __forceinline__ void init_lds(const Params &P, const Ctx &cx, Lds &s) {
     const int lane = cx.lane;
-    s.lut[lane] = P.lut[lane];
-    s.lut[64 + lane] = P.lut[64 + lane];
+    s.lut[lane] = ldg<double>(P.lut, (uint32_t)lane * 8u);
+    s.lut[64 + lane] = ldg<double>(P.lut, (uint32_t)lane * 8u + 512u);
     s.lut[128 + lane] = 0.0;
     s.lut[192 + lane] = 0.0;
     if (lane == 0) s.img[IMG_ZERO] = (uint16_t)(LUT_ABSENT * 8);
@@ -132,14 +151,27 @@ __device__ __forceinline__ void init_lds(const Params &P, const Ctx &cx, Lds &s)
 }
 
 // the descriptor words of this lane for features [chunk*512, chunk*512 + 512)
+// features are encoded two per lane: pair i of a chunk covers features [(chunk*4 + i)*128 + 2*lane, +1]
 __device__ __forceinline__ void load_desc(const Params &P, uint32_t layout, int chunk, int lane, uint32_t (&dsc)[OBS_CHUNK]) {
-    const uint32_t *__restrict__ desc = P.lay_desc + (size_t)layout * P.F;
+    const uint32_t *__restrict__ desc = P.lay_desc + (size_t)layout * (uint32_t)P.F;      // uniform base
+    const uint32_t last_even = ((uint32_t)P.F - 1u) & ~1u;                                // the table is padded by one word
 #pragma unroll
-    for (int i = 0; i < OBS_CHUNK; ++i) dsc[i] = desc[min(chunk * 64 * OBS_CHUNK + 64 * i + lane, P.F - 1)];
+    for (int i = 0; i < OBS_CHUNK / 2; ++i) {
+        const uint32_t fbase = (uint32_t)(chunk * (OBS_CHUNK / 2) + i) * 128u;
+        dsc[2 * i] = 0u; dsc[2 * i + 1] = 0u;
+        if (fbase < (uint32_t)P.F) {                                                      // uniform branch
+            const uint2_t d = ldg<uint2_t>(desc, min(fbase + 2u * (uint32_t)lane, last_even) * 4u);
+            dsc[2 * i] = d.x; dsc[2 * i + 1] = d.y;
+        }
+    }
 }
 
 // cooking_env.py:352-373 get_feature_vector for every agent of the env: out[a][f] = lut[img[desc.hw] - sub[a][desc.code]]
-template <int OPL, int CPL, int NA>
+// WT = write-through stores (`buffer_store_dwordx4 ... sc1`): the observation bytes leave the XCD's L2 while the kernel
+// still computes instead of staying dirty until the end-of-kernel write-back (which serialises ~B / 6 TB/s behind every
+// launch: MI355X_MICROARCH.md "boundary" / "publish-large").  Pays for one launch per step; the fused kernel, whose
+// launch boundary is amortised over T steps, keeps plain stores.
+template <bool WT, int OPL, int CPL, int NA>
 __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, Lds &s,
                                         uint32_t (&dsc)[OBS_CHUNK], double *__restrict__ out /* [A][F] of this env */) {
     uint32_t *img32 = reinterpret_cast<uint32_t *>(s.img);
@@ -167,45 +199,55 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
         const uint32_t fa = ((e.cell[k] >> 5) | (e.cell[k] >> 6)) & 1u;
         img32[(IMG_CELL0 >> 1) + 2 * (cx.lane + 64 * k) + 1] = ((uint32_t)(LUT_ZERO * 8) + (fa << 3)) | ((uint32_t)(LUT_ONE * 8) << 16);
     }
-    // ---- agents: 4 dwords each, and the per-observer subtrahend table
+    // ---- agents: 4 dwords each (lane a builds agent a's), and the per-observer subtrahend table
     {
-        uint32_t aw = 0;
-        int subv = 0;
-        const uint32_t code = (uint32_t)cx.lane & 15u;
-#pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            const uint32_t t = 1u << e.ao[a];
-            aw = wrl((((uint32_t)e.ax[a] << 3) | ((uint32_t)e.ay[a] << 19)) + c01, 4 * a, aw);
-            aw = wrl(f0 + (((t >> 1) & 1u) << 3) + (((t >> 2) & 1u) << 19), 4 * a + 1, aw);
-            aw = wrl(f0 + (((t >> 3) & 1u) << 3) + (((t >> 4) & 1u) << 19), 4 * a + 2, aw);
-            aw = wrl((uint32_t)(LUT_ONE * 8), 4 * a + 3, aw);
-            // axis codes: 1 -> x, 2 -> y, 4+2j -> x unless j == a, 5+2j -> y unless j == a
-            const uint32_t mx = 0x552u & ~(1u << (4 + 2 * a)), my = 0xAA4u & ~(1u << (5 + 2 * a));
-            const int v = (((mx >> code) & 1u) ? (e.ax[a] << 3) : 0) + (((my >> code) & 1u) ? (e.ay[a] << 3) : 0);
-            if ((cx.lane >> 4) == a) subv = v;
+        const uint32_t A = e.agw;
+        const uint32_t t = 1u << ((A >> 16) & 0xFFu);
+        if (cx.lane < NA) {
+            uint32_t *ag = img32 + (IMG_AG0 >> 1) + 4 * cx.lane;
+            ag[0] = (((A & 0xFFu) << 3) | ((A & 0xFF00u) << 11)) + c01;
+            ag[1] = f0 + (((t >> 1) & 1u) << 3) + (((t >> 2) & 1u) << 19);
+            ag[2] = f0 + (((t >> 3) & 1u) << 3) + (((t >> 4) & 1u) << 19);
+            ag[3] = (uint32_t)(LUT_ONE * 8);
         }
-        if (cx.lane < 4 * NA) img32[(IMG_AG0 >> 1) + cx.lane] = aw;
-        if (cx.lane < 16 * NA) (&s.sub[0][0])[cx.lane] = subv;
+        // sub[a][code]: lane 16a + code.  axis codes: 1 -> x, 2 -> y, 4+2j -> x unless j == a, 5+2j -> y unless j == a
+        const uint32_t obs_a = (uint32_t)cx.lane >> 4, code = (uint32_t)cx.lane & 15u;
+        const uint32_t Ao = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(obs_a << 2), (int)A);     // the observer's word
+        const uint32_t mx = 0x552u & ~(1u << (4u + 2u * obs_a)), my = 0xAA4u & ~(1u << (5u + 2u * obs_a));
+        const int v = (int)((((mx >> code) & 1u) ? ((Ao & 0xFFu) << 3) : 0u) + (((my >> code) & 1u) ? ((Ao & 0xFF00u) >> 5) : 0u));
+        if (cx.lane < 16 * NA) (&s.sub[0][0])[cx.lane] = v;
     }
     __builtin_amdgcn_wave_barrier();             // one wave owns this LDS region: DS ops of a wave execute in order
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, NA * P.F * 8, 0x00020000);   // the env's [A][F] block
     const char *lutb = reinterpret_cast<const char *>(s.lut);
     const char *imgb = reinterpret_cast<const char *>(s.img);
     const char *subb = reinterpret_cast<const char *>(s.sub);
     for (int chunk = 0; chunk * 64 * OBS_CHUNK < P.F; ++chunk) {
         if (chunk > 0) load_desc(P, e.layout, chunk, cx.lane, dsc);
 #pragma unroll
-        for (int i = 0; i < OBS_CHUNK; ++i) {
-            const int fbase = chunk * 64 * OBS_CHUNK + 64 * i;
+        for (int i = 0; i < OBS_CHUNK / 2; ++i) {
+            const int fbase = (chunk * (OBS_CHUNK / 2) + i) * 128;
             if (fbase >= P.F) break;
-            const int f = fbase + cx.lane;
-            const uint32_t d = dsc[i];
-            const uint32_t base = *reinterpret_cast<const uint16_t *>(imgb + (d & 0xFFFFu));
-            const bool live = f < P.F;
+            const int f = fbase + 2 * cx.lane;
+            const uint32_t d0 = dsc[2 * i], d1 = dsc[2 * i + 1];
+            const uint32_t b0 = *reinterpret_cast<const uint16_t *>(imgb + (d0 & 0xFFFFu));
+            const uint32_t b1 = *reinterpret_cast<const uint16_t *>(imgb + (d1 & 0xFFFFu));
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
-                const int sub = *reinterpret_cast<const int32_t *>(subb + 64 * a + (d >> 16));
-                const double v = *reinterpret_cast<const double *>(lutb + ((int)base - sub));
-                if (live) out[(size_t)a * P.F + f] = v;
+                const int s0 = *reinterpret_cast<const int32_t *>(subb + 64 * a + (d0 >> 16));
+                const int s1 = *reinterpret_cast<const int32_t *>(subb + 64 * a + (d1 >> 16));
+                double2_t v;
+                v.x = *reinterpret_cast<const double *>(lutb + ((int)b0 - s0));
+                v.y = *reinterpret_cast<const double *>(lutb + ((int)b1 - s1));
+                if (WT) {
+                    const uint32_t soff = (uint32_t)a * (uint32_t)P.F * 8u;
+                    if (f + 1 < P.F) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), rs, (uint32_t)f * 8u, soff, 16);
+                    else if (f < P.F) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, v.x), rs, (uint32_t)f * 8u, soff, 16);
+                } else {
+                    double *row = out + (size_t)a * (uint32_t)P.F;
+                    if (f + 1 < P.F) stg<double2_t>(row, (uint32_t)f * 8u, v);
+                    else if (f < P.F) stg<double>(row, (uint32_t)f * 8u, v.x);
+                }
             }
         }
     }
@@ -220,7 +262,7 @@ struct StepOut {
 
 // One accumulated_step (cooking_env.py:243-269) of one env held in registers.
 template <int OPL, int CPL, int NA, int SCHEME>
-__device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, const Ctx &cx, const int (&acts)[NA],
+__device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t acts,
                                          int64_t env_global, uint32_t &rowv, Lds &lds, uint32_t (&dsc)[OBS_CHUNK], Dirty &dt, StepOut &o) {
     using O = Ops<OPL, CPL, NA, SCHEME>;
 #pragma unroll
@@ -236,7 +278,7 @@ __device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, 
             e.t = 0; e.layout = lay; e.status = 0; e.episode = episode; e.recipes = recipes; e.pool = pool;
             e.marks = all_marks(P, e, cx, rowv, lds);
             if (P.obs) load_desc(P, lay, 0, cx.lane, dsc);
-            dt.cells = 1; dt.touched = 1; dt.interacted = 1;         // everything must be written back
+            dt.cells = 1; dt.touched = 1; dt.interacted = 1; dt.classes = 0xFFFFFFFFu;         // everything must be written back
         } else {
             o.term = (e.status & ST_TERM) ? 1u : 0u;
             o.trunc = (e.status & ST_TRUNC) ? 1u : 0u;
@@ -245,7 +287,7 @@ __device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, 
     }
     o.stepped = true;
     e.t += 1;                                                        // cooking_env.py:244
-#ifdef CZ_PROFILE
+#if defined(CZ_PROFILE)
     const int lane = cx.lane; const long long env = env_global - P.env_id_base;
 #endif
     O::perform_agent_actions(e, cx, acts, dt);                      // cooking_world.py:104-108
@@ -258,17 +300,20 @@ __device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, 
     uint32_t after = before;
 #pragma unroll
     for (int a = 0; a < NA; ++a) o.rew[a] = P.reward_idle;
-    if (dt.touched | (dt.moved & (uint32_t)P.walk_touches)) {
+    if (dt.moved & (uint32_t)P.walk_touches) { dt.touched = 1; dt.classes = 0xFFFFFFFFu; }
+    if (dt.touched) {
         after = 0;
 #pragma nounroll
         for (int r = 0; r < P.R; ++r) {
-            const uint32_t ma = O::recipe_marks(e, cx, rowv, 9 * r, lds.locs);
             const uint32_t mb = (before >> (8 * r)) & 0xFF;
+            // a recipe's marks depend only on objects of its node classes (row word 0 bits 8..: dynamic-class mask)
+            const bool affected = ((rdl(rowv, 9 * r) >> 8) & dt.classes) != 0u;
+            const uint32_t ma = affected ? O::recipe_marks(e, cx, rowv, 9 * r, lds.locs) : mb;
             after |= ma << (8 * r);
             if (ma != mb) {
                 // goals_completed sums (recipe.py:36-40): open goal slots before / after
                 uint32_t countmask = 0;
-                const int n = (int)rdl(rowv, 9 * r);
+                const int n = (int)(rdl(rowv, 9 * r) & 0xFFu);
 #pragma unroll
                 for (int j = 0; j < MAX_NODES; ++j)
                     if (j < n && ((rdl(rowv, 9 * r + 1 + j) >> 24) & 1)) countmask |= 1u << j;
@@ -314,8 +359,8 @@ __global__ __launch_bounds__(256) void k_step(const Params P) {
     double *retp = reinterpret_cast<double *>(rec + RET_WORD0);
     // ---- every load of the step is issued here, before anything waits
     int av = 0;
-    if (!FUSED) av = P.actions[(size_t)env * NA + min(lane, NA - 1)];
-    double ret = retp[lane & 3];                                           // running episode return, lane a = agent a
+    if (!FUSED) av = ldg<int>(P.actions + (size_t)env * NA, (uint32_t)min(lane, NA - 1) * 4u);
+    double ret = ldg<double>(retp, ((uint32_t)lane & 3u) * 8u);                                           // running episode return, lane a = agent a
     Env<OPL, CPL, NA> e;
     load_env(P, e, cx, rec);
     init_lds<CPL>(P, cx, lds);
@@ -329,18 +374,15 @@ __global__ __launch_bounds__(256) void k_step(const Params P) {
     const int T = FUSED ? P.T : 1;
 #pragma nounroll
     for (int t = 0; t < T; ++t) {
-        int acts[NA];
-        if (!FUSED) {
-#pragma unroll
-            for (int a = 0; a < NA; ++a) acts[a] = (int)rdl((uint32_t)av, a) & 7;
-        } else {
-            const uint32_t nact = SCHEME == 3 ? 5u : 8u;
-#pragma unroll
-            for (int a = 0; a < NA; ++a) acts[a] = (int)action_hash(P.seed, env_global, a, P.step0 + (uint32_t)t, nact);
-        }
-        Dirty dt{0, 0, 0, 0, 0};
+        uint32_t acts;                                             // lane a = action of agent a
+        if (!FUSED) acts = (uint32_t)av;
+        else acts = action_hash(P.seed, env_global, lane & 3, P.step0 + (uint32_t)t, SCHEME == 3 ? 5u : 8u);
+        Dirty dt{0, 0, 0, 0, 0, 0};
         StepOut o;
         step_env<OPL, CPL, NA, SCHEME>(P, e, cx, acts, env_global, rowv, lds, dsc, dt, o);
+#if defined(CZ_ABLATE)
+        if (P.stop == 2 || P.stop == 3) return;
+#endif
         CZ_STAMP(4);
         cells_dirty |= dt.cells != 0;
         objs_dirty |= (dt.touched | dt.interacted | dt.moved) != 0;
@@ -365,16 +407,16 @@ __global__ __launch_bounds__(256) void k_step(const Params P) {
         // ---- outputs of this step
         const size_t row = FUSED ? ((size_t)t * P.N + env) : (size_t)env;
         if (lane < NA) {
-            if (P.rewards) P.rewards[row * NA + lane] = myrew;
-            if (P.term) P.term[row * NA + lane] = (uint8_t)o.term;
-            if (P.trunc) P.trunc[row * NA + lane] = (uint8_t)o.trunc;
+            if (P.rewards) stg<double>(P.rewards + row * NA, (uint32_t)lane * 8u, myrew);
+            if (P.term) stg<uint8_t>(P.term + row * NA, (uint32_t)lane, (uint8_t)o.term);
+            if (P.trunc) stg<uint8_t>(P.trunc + row * NA, (uint32_t)lane, (uint8_t)o.trunc);
         }
         CZ_STAMP(5);
-        if (P.obs) observe(P, e, cx, lds, dsc, P.obs + row * (size_t)NA * P.F);
+        if (P.obs) observe<!FUSED>(P, e, cx, lds, dsc, P.obs + row * (size_t)NA * P.F);
         CZ_STAMP(6);
     }
     store_env(P, e, cx, rec, cells_dirty, objs_dirty);
-    if (lane < NA) retp[lane] = ret;
+    if (lane < NA) stg<double>(retp, (uint32_t)lane * 8u, ret);
     CZ_STAMP(7);
 }
 
@@ -403,7 +445,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin,
     if (obs_out) {
         uint32_t dsc[OBS_CHUNK];
         load_desc(P, e.layout, 0, lane, dsc);
-        observe(P, e, cx, lds, dsc, obs_out + (size_t)i * NA * P.F);
+        observe<false>(P, e, cx, lds, dsc, obs_out + (size_t)i * NA * P.F);
     }
 }
 
@@ -419,7 +461,7 @@ __global__ __launch_bounds__(64) void k_observe(const Params P, int64_t env_begi
     load_env(P, e, cx, P.state + (size_t)(env_begin + i) * P.RW);
     uint32_t dsc[OBS_CHUNK];
     load_desc(P, e.layout, 0, lane, dsc);
-    observe(P, e, cx, lds, dsc, obs_out + (size_t)i * NA * P.F);
+    observe<false>(P, e, cx, lds, dsc, obs_out + (size_t)i * NA * P.F);
 }
 
 // launchers exported by each instantiation unit
