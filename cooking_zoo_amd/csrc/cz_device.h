@@ -468,61 +468,70 @@ struct Ops {
 #pragma unroll
         for (int b = 0; b < NA; ++b) cnt += (exy == rdl(exy, b)) ? 1u : 0u;
         if (NA > 1 && cnt > 1u && wk && act != 0u) { act = 0; tx = x; ty = y; c = own; tcv = ocv; }   // now "walks" onto its own cell
-        if (cx.lane < NA) e.agw = (e.agw & 0xFF00FFFFu) | (o << 16);          // lanes >= NA stay 0 (unused agent words)
-        const uint32_t aux0 = act | (tcv << 8) | (c << 16);
-        const uint32_t aux1 = tx | (ty << 8);
-#pragma nounroll
-        for (int a = 0; a < NA; ++a) {
-            const uint32_t A = rdl(e.agw, a), X0 = rdl(aux0, a), lxy = rdl(aux1, a);
-            const int ac = (int)(X0 & 0xFFu);
-            const uint32_t cv0 = (X0 >> 8) & 0xFFu;
-            const int cc = (int)(X0 >> 16);
+        const bool is_agent = cx.lane < NA;
+        if (is_agent) e.agw = (e.agw & 0xFF00FFFFu) | (o << 16);              // lanes >= NA stay 0 (unused agent words)
+        // ---- execution.  The reference resolves agents one after the other (action_scheme3.py:15-16), but a walking
+        // agent only changes its own position, the position of what it carries and Switch bits, while an interacting
+        // agent only changes objects on cells that hold objects, its own hands and READY/TOGGLE bits; collisions were
+        // resolved above.  The two kinds of effects commute, so all walking happens at once (lane a = agent a) and
+        // only the interacting agents are taken serially, in index order.
+        const bool is_walk_act = SCHEME == 3 || (act - 1u < 4u);
+        const bool walks = is_agent && is_walk_act && wk;                 // action_scheme3.py:26-34 (scheme3: also action 0)
+        const uint32_t txy = tx | (ty << 8);
+        if (walks) e.agw = (e.agw & 0xFFFF0000u) | txy;                    // Agent.move_to world_objects.py:793-796
+        uint64_t drag = ballot(walks && act != 0u && (e.agw >> 24) != 0u); // ... which drags what the agent holds
+        while (drag) {
+            const int a = __ffsll((unsigned long long)drag) - 1;
+            drag &= drag - 1;
+            const uint32_t A = rdl(e.agw, a);
+            move_obj(e, cx, (int)(A >> 24) - 1, A & 0xFFFFu);
+            dt.moved = 1;
+        }
+        uint64_t press = ballot(walks && (tcv & CELL_TYPE) == SWITCH);     // Switch.add_content world_objects.py:159-163
+        while (press) {
+            const int a = __ffsll((unsigned long long)press) - 1;
+            press &= press - 1;
+            cell_update(e, cx, (int)rdl(c, a), 0, CELL_ACTIVE, dt);
+            dt.pressed = 1;
+        }
+        uint64_t inter = ballot(is_agent && !walks && (SCHEME == 3 ? act != 0u : act >= 5u));
+        while (inter) {
+            const int a = __ffsll((unsigned long long)inter) - 1;
+            inter &= inter - 1;
+            const uint32_t A = rdl(e.agw, a);
+            const int ac = (int)rdl(act, a);
             Me me{(int)(A & 0xFFu), (int)((A >> 8) & 0xFFu), (int)((A >> 16) & 0xFFu), (int)(A >> 24) - 1};
-            // cell types and Block walkability cannot change before the end of the step, so the byte gathered in the
-            // pre-pass still decides "walkable"; READY / TOGGLE bits may have been changed by an earlier agent
-            const bool is_walk = SCHEME == 3 || (uint32_t)(ac - 1) < 4u;
-            if (is_walk && walkable(cv0)) {
-                // action_scheme3.py:26-34 resolve_walking_action (scheme3: also for action 0, re-pressing a Switch)
-                if (me.h >= 0 && ac != 0) {                             // Agent.move_to world_objects.py:793-796
-                    move_obj(e, cx, me.h, lxy);
-                    dt.moved = 1;
-                }
-                me.x = (int)(lxy & 0xFFu); me.y = (int)(lxy >> 8);
-                if ((cv0 & CELL_TYPE) == SWITCH) {                      // Switch.add_content :159-163
-                    cell_update(e, cx, cc, 0, CELL_ACTIVE, dt);
-                    dt.pressed = 1;
-                }
-            } else if (SCHEME == 3 ? ac != 0 : ac >= 5) {
-                // the cell in front (scheme3: the bumped cell; scheme1: by orientation, may be off-grid)
-                int fx = (int)(lxy & 0xFFu), fy = (int)(lxy >> 8), fc = cc;
-                bool ok = true;
-                if (SCHEME != 3) {
-                    fx = me.x + (int)((DX_TABLE >> (2 * me.o)) & 3u) - 1;
-                    fy = me.y + (int)((DY_TABLE >> (2 * me.o)) & 3u) - 1;
-                    ok = (uint32_t)fx < W && (uint32_t)fy < H;          // reference: IndexError; build: no-op
-                    fc = fy * cx.W + fx;
-                }
-                const uint32_t sv = ok ? cell_at(e, fc) : 0u;
-                if (ok && holds_objects(sv & CELL_TYPE)) {
-                    const uint32_t fxy = (uint32_t)fx | ((uint32_t)fy << 8);
-                    // get_objects_at(location, DynamicObject) cooking_world.py:232-241 as a slot mask
-                    OM dyn = oballot(e, [=](uint32_t w, uint32_t) { return (w & (D_ALIVE | 0xFFFFu)) == (D_ALIVE | fxy); });
-                    if (SCHEME == 3) {
-                        // action_scheme3.py:37-43: ActionObject with a not-done item -> execute, else primary
-                        bool exec = false;
-                        if ((sv & CELL_TYPE) >= CUTBOARD)
-                            exec = (dyn & oballot(e, [](uint32_t w, uint32_t) { return !(w & D_DONE); })).any();
-                        if (exec) execute(e, cx, fx, fy, fc, sv, dyn, dt);
-                        else primary(e, cx, me, fx, fy, fc, sv, dyn, dt);
-                    } else {
-                        if (ac == 5) primary(e, cx, me, fx, fy, fc, sv, dyn, dt);
-                        else if (ac == 6) pick_up_special(e, cx, me, dyn, dt);
-                        else execute(e, cx, fx, fy, fc, sv, dyn, dt);
-                    }
-                }
+            // the cell in front (scheme3: the bumped cell; scheme1: by orientation, may be off-grid)
+            int fx, fy;
+            bool ok = true;
+            if (SCHEME == 3) {
+                const uint32_t lxy = rdl(txy, a);
+                fx = (int)(lxy & 0xFFu); fy = (int)(lxy >> 8);
+            } else {
+                fx = me.x + (int)((DX_TABLE >> (2 * me.o)) & 3u) - 1;
+                fy = me.y + (int)((DY_TABLE >> (2 * me.o)) & 3u) - 1;
+                ok = (uint32_t)fx < W && (uint32_t)fy < H;              // reference: IndexError; build: no-op
             }
-            const uint32_t newA = (uint32_t)me.x | ((uint32_t)me.y << 8) | ((uint32_t)me.o << 16) | ((uint32_t)((me.h + 1) & 0xFF) << 24);
-            e.agw = wrl(newA, a, e.agw);
+            const int fc = fy * cx.W + fx;
+            const uint32_t sv = ok ? cell_at(e, fc) : 0u;               // READY / TOGGLE may have been changed by an earlier agent
+            if (ok && holds_objects(sv & CELL_TYPE)) {
+                const uint32_t fxy = (uint32_t)fx | ((uint32_t)fy << 8);
+                // get_objects_at(location, DynamicObject) cooking_world.py:232-241 as a slot mask
+                OM dyn = oballot(e, [=](uint32_t w, uint32_t) { return (w & (D_ALIVE | 0xFFFFu)) == (D_ALIVE | fxy); });
+                if (SCHEME == 3) {
+                    // action_scheme3.py:37-43: ActionObject with a not-done item -> execute, else primary
+                    bool exec = false;
+                    if ((sv & CELL_TYPE) >= CUTBOARD)
+                        exec = (dyn & oballot(e, [](uint32_t w, uint32_t) { return !(w & D_DONE); })).any();
+                    if (exec) execute(e, cx, fx, fy, fc, sv, dyn, dt);
+                    else primary(e, cx, me, fx, fy, fc, sv, dyn, dt);
+                } else {
+                    if (ac == 5) primary(e, cx, me, fx, fy, fc, sv, dyn, dt);
+                    else if (ac == 6) pick_up_special(e, cx, me, dyn, dt);
+                    else execute(e, cx, fx, fy, fc, sv, dyn, dt);
+                }
+                e.agw = wrl((A & 0x00FFFFFFu) | ((uint32_t)((me.h + 1) & 0xFF) << 24), a, e.agw);   // only the hands can change
+            }
         }
     }
 

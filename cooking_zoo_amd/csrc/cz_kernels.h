@@ -25,7 +25,8 @@ namespace cz {
 // LDS image of one env (halfwords, cooking_zoo_amd/soa.py IMG_*): every halfword is a BYTE offset into `lut`
 constexpr int IMG_OBJ0 = 0, IMG_CELL0 = 768, IMG_AG0 = 1792, IMG_ZERO = 1824, IMG_HALFWORDS = 1832;
 constexpr int LUT_ABSENT = 255, LUT_SIZE = 256;
-constexpr int OBS_CHUNK = 8;       // descriptor words prefetched per lane (8 x 64 = 512 features per chunk)
+constexpr int OBS_PAIRS = 3;       // feature pairs per lane and chunk: 3 x 128 = 384 features per chunk
+constexpr int OBS_CHUNK = 2 * OBS_PAIRS;   // descriptor words held per lane
 
 struct Lds {
     double lut[LUT_SIZE];          // [0..2W-2] (i-(W-1))/W | [64..64+2H-2] (i-(H-1))/H | [126] 0.0 | [127] 1.0 | [128..255] 0.0
@@ -151,7 +152,7 @@ __device__ __forceinline__ void init_lds(const Params &P, const Ctx &cx, Lds &s)
 }
 
 // the descriptor words of this lane for features [chunk*512, chunk*512 + 512)
-// features are encoded two per lane: pair i of a chunk covers features [(chunk*4 + i)*128 + 2*lane, +1]
+// features are encoded two per lane: pair i of a chunk covers features [(chunk*OBS_PAIRS + i)*128 + 2*lane, +1]
 __device__ __forceinline__ void load_desc(const Params &P, uint32_t layout, int chunk, int lane, uint32_t (&dsc)[OBS_CHUNK]) {
     const uint32_t *__restrict__ desc = P.lay_desc + (size_t)layout * (uint32_t)P.F;      // uniform base
     const uint32_t last_even = ((uint32_t)P.F - 1u) & ~1u;                                // the table is padded by one word
@@ -222,31 +223,42 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
     const char *lutb = reinterpret_cast<const char *>(s.lut);
     const char *imgb = reinterpret_cast<const char *>(s.img);
     const char *subb = reinterpret_cast<const char *>(s.sub);
-    for (int chunk = 0; chunk * 64 * OBS_CHUNK < P.F; ++chunk) {
+    for (int chunk = 0; chunk * 128 * OBS_PAIRS < P.F; ++chunk) {
         if (chunk > 0) load_desc(P, e.layout, chunk, cx.lane, dsc);
+        // branch-free stages so that the LDS reads of all pairs and observers are in flight together
+        // (descriptor words past F are 0: they read image halfword 0 and are never stored)
+        uint32_t b[OBS_CHUNK];
 #pragma unroll
-        for (int i = 0; i < OBS_CHUNK / 2; ++i) {
-            const int fbase = (chunk * (OBS_CHUNK / 2) + i) * 128;
-            if (fbase >= P.F) break;
-            const int f = fbase + 2 * cx.lane;
-            const uint32_t d0 = dsc[2 * i], d1 = dsc[2 * i + 1];
-            const uint32_t b0 = *reinterpret_cast<const uint16_t *>(imgb + (d0 & 0xFFFFu));
-            const uint32_t b1 = *reinterpret_cast<const uint16_t *>(imgb + (d1 & 0xFFFFu));
+        for (int j = 0; j < OBS_CHUNK; ++j) b[j] = *reinterpret_cast<const uint16_t *>(imgb + (dsc[j] & 0xFFFFu));
+        int sb[NA][OBS_CHUNK];
 #pragma unroll
-            for (int a = 0; a < NA; ++a) {
-                const int s0 = *reinterpret_cast<const int32_t *>(subb + 64 * a + (d0 >> 16));
-                const int s1 = *reinterpret_cast<const int32_t *>(subb + 64 * a + (d1 >> 16));
-                double2_t v;
-                v.x = *reinterpret_cast<const double *>(lutb + ((int)b0 - s0));
-                v.y = *reinterpret_cast<const double *>(lutb + ((int)b1 - s1));
-                if (WT) {
-                    const uint32_t soff = (uint32_t)a * (uint32_t)P.F * 8u;
-                    if (f + 1 < P.F) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), rs, (uint32_t)f * 8u, soff, 16);
-                    else if (f < P.F) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, v.x), rs, (uint32_t)f * 8u, soff, 16);
-                } else {
-                    double *row = out + (size_t)a * (uint32_t)P.F;
-                    if (f + 1 < P.F) stg<double2_t>(row, (uint32_t)f * 8u, v);
-                    else if (f < P.F) stg<double>(row, (uint32_t)f * 8u, v.x);
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int j = 0; j < OBS_CHUNK; ++j) sb[a][j] = *reinterpret_cast<const int32_t *>(subb + 64 * a + (dsc[j] >> 16));
+        double2_t v[NA][OBS_PAIRS];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int i = 0; i < OBS_PAIRS; ++i) {
+                v[a][i].x = *reinterpret_cast<const double *>(lutb + ((int)b[2 * i] - sb[a][2 * i]));
+                v[a][i].y = *reinterpret_cast<const double *>(lutb + ((int)b[2 * i + 1] - sb[a][2 * i + 1]));
+            }
+#pragma unroll
+        for (int i = 0; i < OBS_PAIRS; ++i) {
+            const int f = (chunk * OBS_PAIRS + i) * 128 + 2 * cx.lane;
+            if (f + 1 < P.F) {
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    if (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v[a][i]), rs, (uint32_t)f * 8u,
+                                                                    (uint32_t)a * (uint32_t)P.F * 8u, 16);
+                    else stg<double2_t>(out + (size_t)a * (uint32_t)P.F, (uint32_t)f * 8u, v[a][i]);
+                }
+            } else if (f < P.F) {                                  // odd F: the last feature stands alone
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    if (WT) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, v[a][i].x), rs, (uint32_t)f * 8u,
+                                                                   (uint32_t)a * (uint32_t)P.F * 8u, 16);
+                    else stg<double>(out + (size_t)a * (uint32_t)P.F, (uint32_t)f * 8u, v[a][i].x);
                 }
             }
         }
