@@ -99,6 +99,7 @@ struct cz_handle_s {
     void *rccl = nullptr;
     void *comm = nullptr;
     int n_ranks = 1, rank = 0;
+    int wt_override = -1;          // CZ_WT experiment switch, read once
     cz_stats *d_gather = nullptr;
     std::string err;
 };
@@ -175,6 +176,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     P.time_penalty_step = cfg->max_time_penalty / (double)cfg->max_steps;       // cooking_env.py:307
     P.T = 1;
     P.stop = -1;
+    if (const char *s = getenv("CZ_WT")) h->wt_override = atoi(s);
     if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // honoured by the diagnostic build only
     h->kl = (P.D <= 64 && C <= 64) ? launchers_small() : launchers_large();
     {   // the reward of a step on which no recipe node changed: cooking_env.py:304-307 with zero deltas, same op order
@@ -249,15 +251,33 @@ extern "C" int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n) {
     if (h->d_recipes) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->d_recipes)); }
     size_t bytes = (size_t)n * (1 + MAX_NODES) * 4;
     HIPCHK(h, hipMalloc(&h->d_recipes, bytes));
-    // device copy: word 0 of every row additionally carries, in bits 8.., the mask of dynamic classes its nodes name
+    // device copy: word 0 = node count | (mask of dynamic classes the nodes name) << 8; node words are re-encoded as
+    // compare masks (layout documented at Ops::recipe_marks in cz_device.h)
     std::vector<uint32_t> dev(table, table + (size_t)n * (1 + MAX_NODES));
     for (int i = 0; i < n; ++i) {
         uint32_t *row = dev.data() + (size_t)i * (1 + MAX_NODES), mask = 0;
-        for (uint32_t j = 0; j < row[0]; ++j) {
-            uint32_t cls = row[1 + j] & 0xFF;
-            if (cls >= 16 && cls < 32) mask |= 1u << (cls - 16);
+        const uint32_t nn = row[0];
+        for (uint32_t j = 0; j < MAX_NODES; ++j) {
+            const uint32_t hw = row[1 + j];
+            const uint32_t cls = hw & 0xFF, cond = (hw >> 8) & 0xFF, children = (hw >> 16) & 0xFF, counts = (hw >> 24) & 1;
+            uint32_t w = (children << 2) | (counts << 10);
+            if (j >= nn) { row[1 + j] = 0; continue; }
+            if (cls < 16) {
+                w |= 0x800u | ((cls & 7u) << 12);
+                if (cls > BLENDER) w |= 0x06000003u;                          // unknown static class: matches nothing
+            } else if (cls < 32) {
+                mask |= 1u << (cls - 16);
+                w |= ((cls - 16) << 16) | D_ALIVE;
+                if (cond == COND_CHOPPED) w |= 1u | D_CHOPPED;
+                else if (cond == COND_MASHED) w |= 2u | D_MASHED;
+                else if (cond == COND_NOT_CHOPPED) w |= 1u;
+                else if (cond == COND_NOT_MASHED) w |= 2u;
+            } else {
+                w |= (0xFFu << 16);                                           // class with no objects (e.g. "Agent"): never alive
+            }
+            row[1 + j] = w;
         }
-        row[0] = (row[0] & 0xFFu) | (mask << 8);
+        row[0] = (nn & 0xFFu) | (mask << 8);
     }
     HIPCHK(h, hipMemcpyAsync(h->d_recipes, dev.data(), bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -342,7 +362,11 @@ static int ready(cz_handle h) {
     return 0;
 }
 
-static int launch_step(cz_handle h, const Params &P) {
+static int launch_step(cz_handle h, Params &P) {
+    // write-through observation stores pay when the launch is short enough for the end-of-kernel L2 write-back to be
+    // exposed: one step of a moderate batch.  (CZ_WT=0/1 overrides, for experiments.)
+    P.wt = (P.actions != nullptr && (size_t)P.N * P.A * P.F * 8 <= ((size_t)128 << 20)) ? 1 : 0;
+    if (h->wt_override >= 0) P.wt = h->wt_override;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->ktime) {
         while (h->kev.size() < h->kev_used + 2) {
@@ -415,21 +439,47 @@ extern "C" int cz_observe(cz_handle h, int64_t b, int64_t c, double *obs) {
     return 0;
 }
 
+static int set_device(cz_handle h) {
+    static thread_local int current = -1;          // hipSetDevice is not free: only when the calling thread switches GPUs
+    if (current != h->cfg.device_id) {
+        HIPCHK(h, hipSetDevice(h->cfg.device_id));
+        current = h->cfg.device_id;
+    }
+    return 0;
+}
+
 extern "C" int cz_step_device(cz_handle h, const int32_t *d_actions, double *d_obs, double *d_rewards, uint8_t *d_term,
                               uint8_t *d_trunc) {
     if (ready(h)) return 1;
     if (!d_actions) return fail(h, "cz_step_device: actions pointer is null");
-    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (set_device(h)) return 1;
     Params P = h->P;
     P.actions = d_actions; P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
     return launch_step(h, P);
+}
+
+// K consecutive steps, one launch each, issued from C: step k reads actions d_actions + k * action_stride (int32 units,
+// wrapping every `action_period` steps) and overwrites the same output buffers.  Same work as K cz_step_device calls
+// without K trips through the host language.
+extern "C" int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_actions, int64_t action_stride, int32_t action_period,
+                                   double *d_obs, double *d_rewards, uint8_t *d_term, uint8_t *d_trunc) {
+    if (ready(h)) return 1;
+    if (!d_actions || K < 1 || action_period < 1) return fail(h, "cz_step_device_many: bad arguments");
+    if (set_device(h)) return 1;
+    Params P = h->P;
+    P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
+    for (int32_t k = 0; k < K; ++k) {
+        P.actions = d_actions + (int64_t)(k % action_period) * action_stride;
+        if (launch_step(h, P)) return 1;
+    }
+    return 0;
 }
 
 extern "C" int cz_rollout(cz_handle h, int32_t T, uint64_t seed, uint32_t step0, double *d_obs, double *d_rewards,
                           uint8_t *d_term, uint8_t *d_trunc) {
     if (ready(h)) return 1;
     if (T < 1) return fail(h, "cz_rollout: T must be >= 1");
-    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (set_device(h)) return 1;
     Params P = h->P;
     P.actions = nullptr; P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc;
     P.T = T; P.seed = seed; P.step0 = step0;

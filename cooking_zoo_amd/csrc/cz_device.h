@@ -67,6 +67,7 @@ struct Params {
     int32_t T;                     // fused steps per launch (1 for cz_step)
     uint32_t step0;
     int32_t dyn0_off, dyn1_off;    // word offsets inside a record
+    int32_t wt;                    // 1: observation stores are write-through (sc1); chosen per launch by the host
     int32_t walk_touches;          // 1 if carrying an object across cells can change a recipe mark (see cz_load_recipes)
     unsigned long long *stamps;    // diagnostic build only: [N][8] s_memtime stamps (nullptr in the shipped library)
     int32_t stop;                  // diagnostic build only: phase index after which the kernel returns (CZ_STOP), else -1
@@ -627,69 +628,76 @@ struct Ops {
     }
 
     // recipe.py:77-104 update_recipe_state for one recipe graph; returns the marks byte (bit j = node j marked).
-    // A node's matched set is kept as a bit set of CELLS (in LDS scratch `locs`, MAX_NODES x CPL words), because the
-    // only thing a parent asks of a child's matches is location equality (recipe.py:103).  Children always follow
-    // their parent in node_list, so one pass from the last node to the first suffices.  Rolled on purpose: this is
-    // the cold path (it runs only on steps that changed an object) and must not bloat the hot path's registers.
-    // rowv: this lane's word of the recipe rows (lane rbase = node count, lane rbase+1+j = node j)
+    // Device node word (built by cz_load_recipes from the host table):
+    //   bit 0 / 1   the compare mask includes CHOPPED / MASHED        bits 2..9  child mask
+    //   bit 10      counts in the goal sum                            bit 11     static class (bits 12..14 = cell type)
+    //   bits 16..26 the value (word & compare mask) must equal: class<<16 | ALIVE | wanted CHOPPED / MASHED bits
+    // A node's matched set is kept as a bit set of CELLS (LDS scratch `locs`), because the only thing a parent asks of
+    // a child's matches is location equality (recipe.py:103).  Children always follow their parent in node_list, so
+    // one pass from the last node to the first suffices.  Rolled: this is a cold path (steps that changed an object of
+    // one of the recipe's classes) and must not bloat the hot path's registers.
     static __device__ __forceinline__ uint32_t recipe_marks(const E &e, const Ctx &cx, uint32_t rowv, int rbase,
                                                             uint64_t *__restrict__ locs) {
         const int n = (int)(rdl(rowv, rbase) & 0xFFu);
         uint32_t marks = 0;
-        uint32_t mycell[OPL];
-#pragma unroll
-        for (int k = 0; k < OPL; ++k) mycell[k] = ((e.d0[k] >> 8) & 0xFFu) * (uint32_t)cx.W + (e.d0[k] & 0xFFu);
 #pragma nounroll
         for (int j = n - 1; j >= 0; --j) {
-            const uint32_t nd = rdl(rowv, rbase + 1 + j);
-            const uint32_t cls = nd & 0xFF, cond = (nd >> 8) & 0xFF, children = (nd >> 16) & 0xFF;
+            const uint32_t w = rdl(rowv, rbase + 1 + j);
+            const uint32_t children = (w >> 2) & 0xFFu;
             if ((marks & children) != children) continue;                 // all(contains.marked)
-            // intersection of the children's location sets
-            CM allow;
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) allow.w[q] = ~0ull;
-            uint32_t ch = children;
-            while (ch) {
-                int c2 = __ffs((int)ch) - 1;
-                ch &= ch - 1;
-#pragma unroll
-                for (int q = 0; q < CPL; ++q) {
-                    uint64_t w = locs[c2 * CPL + q];
-                    allow.w[q] &= ((uint64_t)rfl((uint32_t)(w >> 32)) << 32) | rfl((uint32_t)w);
-                }
-            }
+            const uint32_t cval = w & 0x07FF0000u, cmask = 0x01FF0000u | ((w & 3u) << 25);
             CM here = CM::zero();
-            bool any = false;
-            if (cls < 16) {                                               // a static class: candidates are cells
-#pragma unroll
-                for (int k = 0; k < CPL; ++k)
-                    here.w[k] = ballot((e.cell[k] & CELL_TYPE) == cls && (cx.lane + 64 * k) < cx.C) & allow.w[k];
-                any = here.any();
-            } else if (cls < 32) {                                        // a dynamic class: candidates are slots
-                // class + condition as (word & cmask) == cval on the dyn0 word
-                uint32_t cmask = D_ALIVE | (0xFFu << 16), cval = D_ALIVE | ((cls - 16) << 16);
-                if (cond == COND_CHOPPED) { cmask |= D_CHOPPED; cval |= D_CHOPPED; }
-                else if (cond == COND_MASHED) { cmask |= D_MASHED; cval |= D_MASHED; }
-                else if (cond == COND_NOT_CHOPPED) cmask |= D_CHOPPED;
-                else if (cond == COND_NOT_MASHED) cmask |= D_MASHED;
-                OM m;
-#pragma unroll
-                for (int k = 0; k < OPL; ++k) {
-                    uint64_t wsel = allow.w[0];
-                    if (CPL > 1) {
-#pragma unroll
-                        for (int q = 1; q < CPL; ++q)
-                            if ((mycell[k] >> 6) == (uint32_t)q) wsel = allow.w[q];
-                    }
-                    m.w[k] = ballot((e.d0[k] & cmask) == cval && ((wsel >> (mycell[k] & 63)) & 1));
-                }
+            bool any;
+            if (children == 0u && !(w & 0x800u)) {
+                // leaf of a dynamic class (the common case): no location constraint
+                OM m = oballot(e, [=](uint32_t a, uint32_t) { return (a & cmask) == cval; });
                 any = m.any();
-                if (j > 0) {                                              // the root's locations are never consulted
-                    while (m.any()) {                                     // a handful of objects at most
-                        int s = m.first();
+                while (j > 0 && m.any()) {                                 // record where the matches are (a handful at most)
+                    const int s = m.first();
+                    m.clear(s);
+                    const uint32_t o = slot_d0(e, s);
+                    here.set((int)(((o >> 8) & 0xFFu) * (uint32_t)cx.W + (o & 0xFFu)));
+                }
+            } else {
+                // intersection of the children's location sets
+                CM allow;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) allow.w[q] = ~0ull;
+                uint32_t ch = children;
+                while (ch) {
+                    const int c2 = __ffs((int)ch) - 1;
+                    ch &= ch - 1;
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) {
+                        const uint64_t lw = locs[c2 * CPL + q];
+                        allow.w[q] &= ((uint64_t)rfl((uint32_t)(lw >> 32)) << 32) | rfl((uint32_t)lw);
+                    }
+                }
+                if (w & 0x800u) {                                         // a static class: candidates are cells
+                    const uint32_t cls = (w >> 12) & 7u;
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k)
+                        here.w[k] = ballot((e.cell[k] & CELL_TYPE) == cls && (cx.lane + 64 * k) < cx.C) & allow.w[k];
+                    any = here.any();
+                } else {                                                  // a dynamic class with children
+                    OM m;
+#pragma unroll
+                    for (int k = 0; k < OPL; ++k) {
+                        const uint32_t mycell = ((e.d0[k] >> 8) & 0xFFu) * (uint32_t)cx.W + (e.d0[k] & 0xFFu);
+                        uint64_t wsel = allow.w[0];
+                        if (CPL > 1) {
+#pragma unroll
+                            for (int q = 1; q < CPL; ++q)
+                                if ((mycell >> 6) == (uint32_t)q) wsel = allow.w[q];
+                        }
+                        m.w[k] = ballot((e.d0[k] & cmask) == cval && ((wsel >> (mycell & 63)) & 1));
+                    }
+                    any = m.any();
+                    while (j > 0 && m.any()) {
+                        const int s = m.first();
                         m.clear(s);
-                        uint32_t w = slot_d0(e, s);
-                        here.set((int)(((w >> 8) & 0xFFu) * (uint32_t)cx.W + (w & 0xFFu)));
+                        const uint32_t o = slot_d0(e, s);
+                        here.set((int)(((o >> 8) & 0xFFu) * (uint32_t)cx.W + (o & 0xFFu)));
                     }
                 }
             }

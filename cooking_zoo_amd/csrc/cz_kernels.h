@@ -168,11 +168,12 @@ __device__ __forceinline__ void load_desc(const Params &P, uint32_t layout, int 
 }
 
 // cooking_env.py:352-373 get_feature_vector for every agent of the env: out[a][f] = lut[img[desc.hw] - sub[a][desc.code]]
-// WT = write-through stores (`buffer_store_dwordx4 ... sc1`): the observation bytes leave the XCD's L2 while the kernel
+// P.wt = write-through stores (`buffer_store_dwordx4 ... sc1`): the observation bytes leave the XCD's L2 while the kernel
 // still computes instead of staying dirty until the end-of-kernel write-back (which serialises ~B / 6 TB/s behind every
 // launch: MI355X_MICROARCH.md "boundary" / "publish-large").  Pays for one launch per step; the fused kernel, whose
-// launch boundary is amortised over T steps, keeps plain stores.
-template <bool WT, int OPL, int CPL, int NA>
+// launch boundary is amortised over T steps, and large batches, whose stores drain while other waves still compute,
+// keep plain stores (policy in cz_api.hip launch_step).
+template <int OPL, int CPL, int NA>
 __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, Lds &s,
                                         uint32_t (&dsc)[OBS_CHUNK], double *__restrict__ out /* [A][F] of this env */) {
     uint32_t *img32 = reinterpret_cast<uint32_t *>(s.img);
@@ -220,6 +221,7 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
     }
     __builtin_amdgcn_wave_barrier();             // one wave owns this LDS region: DS ops of a wave execute in order
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, NA * P.F * 8, 0x00020000);   // the env's [A][F] block
+    const bool wt = P.wt != 0;                                                          // wave-uniform
     const char *lutb = reinterpret_cast<const char *>(s.lut);
     const char *imgb = reinterpret_cast<const char *>(s.img);
     const char *subb = reinterpret_cast<const char *>(s.sub);
@@ -249,14 +251,14 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
             if (f + 1 < P.F) {
 #pragma unroll
                 for (int a = 0; a < NA; ++a) {
-                    if (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v[a][i]), rs, (uint32_t)f * 8u,
+                    if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v[a][i]), rs, (uint32_t)f * 8u,
                                                                     (uint32_t)a * (uint32_t)P.F * 8u, 16);
                     else stg<double2_t>(out + (size_t)a * (uint32_t)P.F, (uint32_t)f * 8u, v[a][i]);
                 }
             } else if (f < P.F) {                                  // odd F: the last feature stands alone
 #pragma unroll
                 for (int a = 0; a < NA; ++a) {
-                    if (WT) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, v[a][i].x), rs, (uint32_t)f * 8u,
+                    if (wt) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, v[a][i].x), rs, (uint32_t)f * 8u,
                                                                    (uint32_t)a * (uint32_t)P.F * 8u, 16);
                     else stg<double>(out + (size_t)a * (uint32_t)P.F, (uint32_t)f * 8u, v[a][i].x);
                 }
@@ -328,7 +330,7 @@ __device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, 
                 const int n = (int)(rdl(rowv, 9 * r) & 0xFFu);
 #pragma unroll
                 for (int j = 0; j < MAX_NODES; ++j)
-                    if (j < n && ((rdl(rowv, 9 * r + 1 + j) >> 24) & 1)) countmask |= 1u << j;
+                    if (j < n && ((rdl(rowv, 9 * r + 1 + j) >> 10) & 1)) countmask |= 1u << j;
                 const int goals_before = __popc(~mb & countmask), goals_after = __popc(~ma & countmask);
                 const bool completed = ma & 1, completion_before = mb & 1;
                 const bool malus = !completed && completion_before, bonus = completed && !completion_before;
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(256) void k_step(const Params P) {
             if (P.trunc) stg<uint8_t>(P.trunc + row * NA, (uint32_t)lane, (uint8_t)o.trunc);
         }
         CZ_STAMP(5);
-        if (P.obs) observe<!FUSED>(P, e, cx, lds, dsc, P.obs + row * (size_t)NA * P.F);
+        if (P.obs) observe(P, e, cx, lds, dsc, P.obs + row * (size_t)NA * P.F);
         CZ_STAMP(6);
     }
     store_env(P, e, cx, rec, cells_dirty, objs_dirty);
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin,
     if (obs_out) {
         uint32_t dsc[OBS_CHUNK];
         load_desc(P, e.layout, 0, lane, dsc);
-        observe<false>(P, e, cx, lds, dsc, obs_out + (size_t)i * NA * P.F);
+        observe(P, e, cx, lds, dsc, obs_out + (size_t)i * NA * P.F);
     }
 }
 
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(64) void k_observe(const Params P, int64_t env_begi
     load_env(P, e, cx, P.state + (size_t)(env_begin + i) * P.RW);
     uint32_t dsc[OBS_CHUNK];
     load_desc(P, e.layout, 0, lane, dsc);
-    observe<false>(P, e, cx, lds, dsc, obs_out + (size_t)i * NA * P.F);
+    observe(P, e, cx, lds, dsc, obs_out + (size_t)i * NA * P.F);
 }
 
 // launchers exported by each instantiation unit

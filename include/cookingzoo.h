@@ -115,6 +115,11 @@ int cz_step(cz_handle h, const int32_t *actions, double *obs, double *rewards, u
 int cz_step_device(cz_handle h, const int32_t *d_actions, double *d_obs, double *d_rewards,
                    uint8_t *d_terminations, uint8_t *d_truncations);
 
+/* K consecutive steps, one launch each, issued from C: step k reads its actions at d_actions + (k % action_period) *
+ * action_stride (in int32 elements) and overwrites the same output buffers.  Equivalent to K cz_step_device calls. */
+int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_actions, int64_t action_stride, int32_t action_period,
+                        double *d_obs, double *d_rewards, uint8_t *d_terminations, uint8_t *d_truncations);
+
 /* T fused steps in one launch with on-device uniform random actions (counter-based stream keyed by
  * (seed, global env id, agent, step0 + t)); state stays in registers between steps.  d_obs, if not NULL,
  * is a trajectory buffer [T][N][A][F]; d_rewards [T][N][A]; d_term/d_trunc [T][N][A] (each may be NULL

@@ -219,3 +219,33 @@ def test_properties_at_baseline_size():
     assert s["episodes"] == 512 and s["truncations"] + s["terminations"] >= 512
     env.close()
     env2.close()
+
+
+@pytest.mark.parametrize("scheme,agents,level,meta,recipes,n,T,ms", [
+    ("scheme3", 2, "coop_test", "example", ["TomatoLettuceSalad", "CarrotBanana"], 2048, 900, 400),
+    ("scheme1", 2, "coexistence_test", "example", ["MashedCarrotBanana", "AppleWatermelon"], 1024, 500, 120),
+    ("scheme3", 4, "large_16x16", "large_16x16", ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"], 512, 400, 150),
+    ("scheme3", 3, "crowded_6x5", "crowded_6x5", ["TomatoSalad", "no_recipe", "MashedCarrotBanana"], 1024, 600, 90),
+])
+def test_long_fused_rollout_matches_oracle(scheme, agents, level, meta, recipes, n, T, ms):
+    """Long horizons at scale (millions of env-steps per case): final state, last observation and statistics of a
+    fused device rollout against the oracle's rollout over the same counter-based action stream."""
+    seed = 2024
+    env = make(n, level=level, meta_file=meta, num_agents=agents, recipes=recipes, action_scheme=scheme, max_steps=ms,
+               num_layouts=64)
+    orc = oracle_for(env)
+    env.reset(return_obs=False)
+    orc.reset()
+    d_obs = env.alloc((n, agents, env.F), np.float64)
+    chunk = 100
+    for t0 in range(0, T, chunk):
+        k = min(chunk, T - t0)
+        env.rollout(k, seed, t0)
+    env.sync()
+    oo, ro, to, uo = orc.rollout(T, seed, 0)
+    assert np.array_equal(strip(env.get_state()), orc.records)
+    assert np.array_equal(bits(env.observe()), bits(oo))
+    st = env.stats()
+    assert st["episodes"] == int(orc.records[:, soa.W_EPISODE].sum()) + int((orc.records[:, soa.W_STATUS] & 1).sum())
+    assert st["env_steps"] > 0.9 * n * T * (ms / (ms + 1.0)) - n
+    env.close()
