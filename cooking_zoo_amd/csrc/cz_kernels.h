@@ -25,6 +25,10 @@ namespace cz {
 // LDS image of one env (halfwords, cooking_zoo_amd/soa.py IMG_*): every halfword is a BYTE offset into `lut`
 constexpr int IMG_OBJ0 = 0, IMG_CELL0 = 768, IMG_AG0 = 1792, IMG_ZERO = 1824, IMG_HALFWORDS = 1832;
 constexpr int LUT_ABSENT = 255, LUT_SIZE = 256;
+#ifndef CZ_ENVS_PER_WG
+#define CZ_ENVS_PER_WG 8
+#endif
+constexpr int ENVS_PER_WG = CZ_ENVS_PER_WG;   // one wavefront per env, this many per workgroup (no cross-wave communication)
 constexpr int OBS_PAIRS = 3;       // feature pairs per lane and chunk: 3 x 128 = 384 features per chunk
 constexpr int OBS_CHUNK = 2 * OBS_PAIRS;   // descriptor words held per lane
 
@@ -357,14 +361,14 @@ __device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, 
     }
 }
 
-// Four envs per 256-thread workgroup (one wavefront each, no cross-wave communication).
+// ENVS_PER_WG envs per workgroup (one wavefront each, no cross-wave communication).
 // FUSED = false: one step, actions from memory.  FUSED = true: P.T steps, on-device action stream, outputs [t][env].
 template <int OPL, int CPL, int NA, int SCHEME, bool FUSED>
-__global__ __launch_bounds__(256) void k_step(const Params P) {
-    __shared__ Lds lds_all[4];
+__global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(const Params P) {
+    __shared__ Lds lds_all[ENVS_PER_WG];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = (int)rfl(threadIdx.x >> 6);
-    const int env = (int)blockIdx.x * 4 + wave;
+    const int env = (int)blockIdx.x * ENVS_PER_WG + wave;
     if (env >= P.N) return;
     Lds &lds = lds_all[wave];
     Ctx cx{P.W, P.H, P.D, P.W * P.H, lane};
@@ -489,7 +493,7 @@ template <int OPL, int CPL>
 struct Inst {
     template <int NA>
     static hipError_t step_na(const Params &P, hipStream_t st) {
-        const dim3 grid((unsigned)((P.N + 3) / 4)), block(256);
+        const dim3 grid((unsigned)((P.N + ENVS_PER_WG - 1) / ENVS_PER_WG)), block(64 * ENVS_PER_WG);
         if (P.actions) {
             if (P.scheme == 3) hipLaunchKernelGGL((k_step<OPL, CPL, NA, 3, false>), grid, block, 0, st, P);
             else hipLaunchKernelGGL((k_step<OPL, CPL, NA, 1, false>), grid, block, 0, st, P);
