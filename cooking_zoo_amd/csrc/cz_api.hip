@@ -248,7 +248,7 @@ extern "C" int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n) {
     for (int i = 0; i < n; ++i)
         if (table[(size_t)i * (1 + MAX_NODES)] > MAX_NODES) return fail(h, "cz_load_recipes: recipe %d has more than 8 nodes", i);
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    if (h->d_recipes) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->d_recipes)); }
+    if (h->d_recipes) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->d_recipes)); h->d_recipes = nullptr; h->P.recipes = nullptr; }
     size_t bytes = (size_t)n * (1 + MAX_NODES) * 4;
     HIPCHK(h, hipMalloc(&h->d_recipes, bytes));
     // device copy: word 0 = node count | (mask of dynamic classes the nodes name) << 8; node words are re-encoded as
@@ -305,11 +305,7 @@ extern "C" int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n) {
 }
 
 extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const uint32_t *obs_desc, int32_t n) {
-    if (!h || !init_records || !obs_desc || n < 1) return fail(h, "cz_load_layouts: bad arguments");
-    HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->d_lay_init) HIPCHK(h, hipFree(h->d_lay_init));
-    if (h->d_lay_desc) HIPCHK(h, hipFree(h->d_lay_desc));
+    if (!h || !init_records || !obs_desc || n < 1 || n > 65535) return fail(h, "cz_load_layouts: bad arguments");
     // validate descriptors: halfword indices must address a slot / cell / agent of this batch, axis codes must exist
     for (size_t i = 0; i < (size_t)n * h->P.F; ++i) {
         uint32_t off = obs_desc[i] & 0xFFFFu, code4 = obs_desc[i] >> 16;
@@ -321,6 +317,10 @@ extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const 
         else ok = ok && hw == (uint32_t)IMG_ZERO;
         if (!ok) return fail(h, "cz_load_layouts: bad observation descriptor %#x at %zu", obs_desc[i], i);
     }
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_lay_init) { HIPCHK(h, hipFree(h->d_lay_init)); h->d_lay_init = nullptr; h->P.lay_init = nullptr; }
+    if (h->d_lay_desc) { HIPCHK(h, hipFree(h->d_lay_desc)); h->d_lay_desc = nullptr; h->P.lay_desc = nullptr; }
     size_t b0 = (size_t)n * h->P.RW * 4, b1 = (size_t)n * h->P.F * 4;
     HIPCHK(h, hipMalloc(&h->d_lay_init, b0));
     HIPCHK(h, hipMalloc(&h->d_lay_desc, b1 + 16));                 // + padding: descriptors are fetched in pairs

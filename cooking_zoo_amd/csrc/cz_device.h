@@ -10,14 +10,17 @@
 //     ballot; a field of one object is a v_readlane; a mutation is a predicated write by the owning lane.
 //   * agents are resolved serially in index order (action_scheme3.py:15-16) -- semantics demand it --
 //     but each agent's work is O(1) wave instructions instead of O(objects) scans.
-//   * the step is instruction-issue bound (profiles/r01), so the common path is kept short: agent count and
-//     action scheme are compile-time, one rolled copy of the interaction code serves every agent, and the
-//     recipe graphs / free-flag normalisation are re-evaluated only when an object actually changed
-//     (both are pure functions of object state, so skipping them on untouched steps is exact).
-//   * the feature-vector encode (cooking_env.py:352-373) walks a per-layout descriptor table: lanes stride
-//     over the F output doubles, gather one word of an LDS image of the final state, turn it into an index
-//     into an LDS table of correctly rounded quotients d/W, d/H (IEEE f64 division, done once per wave)
-//     and the constants 0.0 / 1.0, and store coalesced 8-byte values.
+//   * agents live in one VGPR (lane a = agent a): orientation, target cell, bounds, walkability (ds_bpermute into
+//     the cell lanes) and collisions are computed for all agents at once; all walking happens at once too, because
+//     walking and interacting commute (see perform_agent_actions); only interacting agents are taken serially.
+//   * the launch is latency-bound at a few thousand envs (profiles/r01), so the common path is kept short: agent
+//     count and action scheme are compile-time, and the recipe graphs / free-flag normalisation are re-evaluated only
+//     when an object they depend on actually changed (both are pure functions of object state, so skipping them on
+//     untouched steps is exact).
+//   * the feature-vector encode (cooking_env.py:352-373) walks a per-layout descriptor table: lanes stride over the F
+//     output doubles two at a time, read one halfword of an LDS image of the final state (a byte offset into a table
+//     of correctly rounded quotients d/W, d/H and the constants 0.0 / 1.0, computed on the host), subtract the
+//     observer's coordinate where the feature is relative, and store coalesced 16-byte values (cz_kernels.h).
 // Integer / indexing work only; no MFMA.  No CPU fallback exists in this file or its callers.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -185,21 +188,6 @@ struct Dirty {                     // what this step changed (uniform)
     uint32_t moved;                // a held object was carried to another cell  -> objects must be written back
     uint32_t classes;              // bit c: an object of dynamic class c moved or changed state (recipe filter); ~0 = any
 };
-
-template <int NA>
-__device__ __forceinline__ int sel(const int (&a)[NA], int i) {
-    int v = a[0];
-#pragma unroll
-    for (int k = 1; k < NA; ++k)
-        if (i == k) v = a[k];
-    return v;
-}
-template <int NA>
-__device__ __forceinline__ void put(int (&a)[NA], int i, int v) {
-#pragma unroll
-    for (int k = 0; k < NA; ++k)
-        if (NA == 1 || i == k) a[k] = v;
-}
 
 // dx + 1 / dy + 1 of get_target_location (cooking_world.py:172-184), two bits per action code 0..7
 constexpr uint32_t DX_TABLE = 0x5561u, DY_TABLE = 0x5495u;

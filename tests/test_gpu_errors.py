@@ -1,0 +1,67 @@
+"""GPU: error behaviour of the C-ABI (non-zero return + message), mirrored as Python exceptions by the binding."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cooking_zoo_amd import _native
+
+pytestmark = pytest.mark.gpu
+
+
+def cfg(**kw):
+    base = dict(num_envs=4, num_agents=2, width=7, height=7, max_dyn=12, feat_len=278, action_scheme=3, max_steps=10,
+                end_condition_all=0, num_recipes=2, auto_reset=0, device_id=0, env_id_base=0, recipe_reward=20.0,
+                max_time_penalty=-5.0, recipe_penalty=-40.0, recipe_node_reward=0.0)
+    base.update(kw)
+    return _native.CzConfig(*[base[f[0]] for f in _native.CzConfig._fields_])
+
+
+@pytest.mark.parametrize("bad,msg", [
+    (dict(num_agents=5), "num_agents"), (dict(num_recipes=1), "num_recipes"), (dict(width=40), "grid"),
+    (dict(max_dyn=200), "max_dyn"), (dict(action_scheme=2), "scheme2"), (dict(device_id=99), "device_id"),
+    (dict(num_envs=0), "num_envs"),
+])
+def test_create_rejects_bad_config(bad, msg):
+    L = _native.lib()
+    h = C.c_void_p()
+    c = cfg(**bad)
+    assert L.cz_create(C.byref(c), C.byref(h)) != 0
+    assert msg in L.cz_last_error(None).decode()
+
+
+def test_calls_before_tables_and_bad_ranges():
+    L = _native.lib()
+    h = C.c_void_p()
+    c = cfg()
+    assert L.cz_create(C.byref(c), C.byref(h)) == 0
+    acts = np.zeros((4, 2), np.int32)
+    rew = np.zeros((4, 2)); te = np.zeros((4, 2), np.uint8); tr = np.zeros((4, 2), np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert L.cz_step(h, p(acts), None, p(rew), p(te), p(tr)) != 0 and b"recipes not loaded" in L.cz_last_error(h)
+    recs = np.zeros((2, L.cz_record_words(h)), np.uint32)
+    assert L.cz_get_state(h, 3, 2, p(recs)) != 0 and b"outside" in L.cz_last_error(h)
+    bad_table = np.zeros((1, 9), np.uint32); bad_table[0, 0] = 9
+    assert L.cz_load_recipes(h, p(bad_table), 1) != 0 and b"more than 8 nodes" in L.cz_last_error(h)
+    with pytest.raises(_native.NativeError):
+        _native.check(h, 1)
+    assert L.cz_destroy(h) == 0
+
+
+def test_bad_descriptor_and_ids_are_rejected():
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    env = CookingVecEnv(4, "coop_test", "example", 2, 10, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3",
+                        num_layouts=2)
+    L, h = _native.lib(), env._h
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    desc = env._lay_desc.copy()
+    desc[0, 0] = 0xFFFF0001
+    assert L.cz_load_layouts(h, p(env._lay_records), p(desc), 2) != 0 and b"bad observation descriptor" in L.cz_last_error(h)
+    env._upload_layouts()
+    with pytest.raises(_native.NativeError, match="layout id"):
+        env.reset(layout_ids=[0, 1, 2, 0])
+    with pytest.raises(Exception):
+        CookingVecEnv(4, "coop_test", "example", 2, 10, ["TomatoLettuceSalad"], action_scheme="scheme3")   # one recipe per agent
+    with pytest.raises(ValueError, match="scheme2"):
+        CookingVecEnv(4, "coop_test", "example", 2, 10, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme2")
+    env.close()

@@ -130,3 +130,26 @@ def test_action_stream_matches_oracle():
         for ep in range(5):
             for pool in (0, 3 | (5 << 16)):
                 assert o.czo_next_layout(e, ep, pool, 11) == L.cz_next_layout(e, ep, pool, 11)
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    """No CPU fallback: without the HIP library the product path raises (it never reaches for the oracle)."""
+    import importlib
+    import subprocess
+    import sys
+    code = ("import os, sys; os.environ['CZ_LIB'] = '/nonexistent/libcookingzoo_hip.so'; sys.path.insert(0, %r);"
+            "from cooking_zoo_amd.vec_env import CookingVecEnv\n"
+            "try:\n    CookingVecEnv(2, 'coop_test', 'example', 1, 10, ['TomatoSalad'], action_scheme='scheme3')\n"
+            "except Exception as e:\n    print(type(e).__name__, str(e)[:60]); sys.exit(0)\nsys.exit(3)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and "NativeError" in out.stdout and "not found" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under cooking_zoo_amd/ may mention it."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cooking_zoo_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_binding" not in text and "libcz_oracle" not in text and "czo_" not in text.replace("czo_action", ""), f
