@@ -42,7 +42,7 @@ def level_max_dyn(level_object) -> int:
     for entry in level_object["DYNAMIC_OBJECTS"]:
         (name, spec), = entry.items()
         n += spec["COUNT"] * (2 if name == "Bread" else 1)
-    return n
+    return max(n, 1)          # the record always has at least one (possibly unused) slot
 
 
 def instantiate(level_object, meta: dict, num_agents: int, rng=_random) -> Layout:

@@ -345,7 +345,7 @@ def level_max_dyn(level_path_or_name):
     for d in lv["DYNAMIC_OBJECTS"]:
         (name, spec), = d.items()
         n += spec["COUNT"] * (2 if name == "Bread" else 1)
-    return n
+    return max(n, 1)          # the record always has at least one (possibly unused) slot
 
 
 def capture_episode(cfg, seed, policy_name, max_len=None):
@@ -571,6 +571,18 @@ def main():
                      max_steps=200, meta=metac),
             [(130, "uniform", 200), (131, "bumper", 200)], args.out)
 
+    metae = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", "edge.json")
+    for ename, agents, recipes in (("edge_8x8", 3, ["TomatoSalad", "MashedCarrotBanana", "TomatoLettuceSalad"]),
+                                   ("edge_9x8", 3, ["TomatoSalad", "CarrotBanana", "TomatoLettuceSalad"]),
+                                   ("edge_empty", 2, ["TomatoSalad", "no_recipe"])):
+        elvl = os.path.join(REPO, "cooking_zoo_amd", "utils", "level", ename + ".json")
+        if os.path.exists(elvl) and os.path.exists(metae):
+            sets[ename] = (lambda n=ename, l=elvl, a=agents, r=recipes: run_set(
+                n, base_cfg(l, a, r, max_steps=120, meta=metae),
+                [(200, "bumper", 120), (201, "uniform", 120), (202, "bumper", 120)], args.out))
+            sets[ename + "_scheme1"] = (lambda n=ename, l=elvl, a=agents, r=recipes: run_set(
+                n + "_scheme1", base_cfg(l, a, r, scheme="scheme1", max_steps=100, meta=metae),
+                [(210, "bumper", 100), (211, "uniform", 100)], args.out))
     sets["api_traces"] = lambda: api_traces(args.out)
     sets["layouts_ref"] = lambda: layout_draws(args.out)
     for name, fn in sets.items():

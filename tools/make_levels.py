@@ -78,6 +78,35 @@ def crowded_6x5():
     return lv, meta
 
 
+def edge_levels():
+    """boundary sizes: 8x8 = 64 cells (last one-cell-per-lane size), 9x8 = 72 cells (first multi-cell size),
+    and a level without any dynamic object"""
+    out = {}
+    one = lambda name, x, y: {name: {"COUNT": 1, "X_POSITION": [x], "Y_POSITION": [y]}}
+    for name, W, H in (("edge_8x8", 8, 8), ("edge_9x8", 9, 8)):
+        rows = ["-" * W] + ["-" + " " * (W - 2) + "-" for _ in range(H - 2)] + ["-" * W]
+        statics = [one("Cutboard", 0, 2), one("Cutboard", W - 1, 5), one("Blender", 3, H - 1), one("Deliversquare", 4, 0),
+                   one("Switch", 2, 3), one("Block", W - 3, 4)]
+        dyn = [{"Plate": {"COUNT": 2, "X_POSITION": [0, W - 1], "Y_POSITION": list(range(1, H - 1))}},
+               {"Tomato": {"COUNT": 2, "X_POSITION": list(range(1, W - 1)), "Y_POSITION": [0, H - 1]}},
+               {"Carrot": {"COUNT": 1, "X_POSITION": list(range(1, W - 1)), "Y_POSITION": [0, H - 1]}},
+               {"Banana": {"COUNT": 1, "X_POSITION": [0, W - 1], "Y_POSITION": list(range(1, H - 1))}},
+               {"Bread": {"COUNT": 2, "X_POSITION": list(range(1, W - 1)), "Y_POSITION": [0, H - 1], "OPTIONAL": 0.8}},
+               {"Lettuce": {"COUNT": 1, "X_POSITION": [0, W - 1], "Y_POSITION": list(range(1, H - 1))}}]
+        cells = {"X_POSITION": list(range(1, W - 1)), "Y_POSITION": list(range(1, H - 1))}
+        lv = {"LEVEL_LAYOUT": "\n".join(rows), "STATIC_OBJECTS": statics, "DYNAMIC_OBJECTS": dyn,
+              "AGENTS": [dict(MAX_COUNT=1, **cells) for _ in range(3)],
+              "DYNAMIC_EXCLUDED_POSITIONS": [[0, 0], [W - 1, 0], [0, H - 1], [W - 1, H - 1]]}
+        out[name] = lv
+    rows = ["-----", "-   -", "-   -", "-----"]
+    out["edge_empty"] = {"LEVEL_LAYOUT": "\n".join(rows), "STATIC_OBJECTS": [one("Deliversquare", 2, 0), one("Cutboard", 0, 1)],
+                         "DYNAMIC_OBJECTS": [], "AGENTS": [{"MAX_COUNT": 2, "X_POSITION": [1, 2, 3], "Y_POSITION": [1, 2]}],
+                         "DYNAMIC_EXCLUDED_POSITIONS": []}
+    meta = [{"Switch": 1}, {"Block": 1}, {"Agent": 3}, {"Cutboard": 2}, {"Counter": 30}, {"Blender": 1}, {"Deliversquare": 1},
+            {"Plate": 2}, {"Tomato": 2}, {"Carrot": 1}, {"Banana": 1}, {"Bread": 4}, {"Lettuce": 1}]
+    return out, meta
+
+
 def main():
     os.makedirs(LEVEL_DIR, exist_ok=True)
     os.makedirs(META_DIR, exist_ok=True)
@@ -87,6 +116,10 @@ def main():
     lv, meta = crowded_6x5()
     dump_level(os.path.join(LEVEL_DIR, "crowded_6x5.json"), lv)
     dump_meta(os.path.join(META_DIR, "crowded_6x5.json"), meta)
+    levels, meta = edge_levels()
+    for name, lv in levels.items():
+        dump_level(os.path.join(LEVEL_DIR, name + ".json"), lv)
+    dump_meta(os.path.join(META_DIR, "edge.json"), meta)
     if os.path.isdir(REF):
         for name in ("coop_test", "coexistence_test", "switch_test"):
             with open(os.path.join(REF, "level", name + ".json")) as f:
