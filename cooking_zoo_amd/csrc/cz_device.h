@@ -85,12 +85,15 @@ __device__ __forceinline__ uint32_t wrl(uint32_t value, int lane, uint32_t into)
 
 // counter-based action stream (host mirror: cz_action in cz_api.hip, oracle mirror: czo_action)
 __host__ __device__ inline uint32_t action_hash(uint64_t seed, int64_t env_global, int agent, uint32_t step, uint32_t n) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)env_global * 4u + (uint64_t)agent + 1u) +
-                 0xD1B54A32D192ED03ull * ((uint64_t)step + 1u);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(((z >> 32) * (uint64_t)n) >> 32);
+    /* counter-based: two rounds of a 32-bit avalanche mixer over (seed, env, agent, step) */
+    uint32_t x = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u);
+    x ^= (uint32_t)env_global * 0x85EBCA6Bu + (uint32_t)((uint64_t)env_global >> 32) * 0x27D4EB2Fu;
+    x ^= ((uint32_t)agent + 1u) * 0xC2B2AE35u;
+    x ^= (step + 1u) * 0x165667B1u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    x += step * 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return (uint32_t)(((uint64_t)x * (uint64_t)n) >> 32);
 }
 __host__ __device__ inline uint32_t next_layout(int64_t env_global, uint32_t episode, uint32_t pool_word, uint32_t n_layouts) {
     uint32_t base = pool_word & 0xFFFFu, count = pool_word >> 16;

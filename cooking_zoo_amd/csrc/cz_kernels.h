@@ -179,12 +179,14 @@ __device__ __forceinline__ void load_desc(const Params &P, uint32_t layout, int 
 // keep plain stores (policy in cz_api.hip launch_step).
 template <int OPL, int CPL, int NA>
 __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, Lds &s,
-                                        uint32_t (&dsc)[OBS_CHUNK], double *__restrict__ out /* [A][F] of this env */) {
+                                        uint32_t (&dsc)[OBS_CHUNK], double *__restrict__ out /* [A][F] of this env */,
+                                        bool objs_changed = true, bool cells_changed = true) {
     uint32_t *img32 = reinterpret_cast<uint32_t *>(s.img);
     const uint32_t dead = (uint32_t)(LUT_ABSENT * 8) * 0x10001u;
     const uint32_t c01 = (uint32_t)((P.W - 1) * 8) | ((uint32_t)((LUT_Y0 + P.H - 1) * 8) << 16);
     const uint32_t f0 = (uint32_t)(LUT_ZERO * 8) * 0x10001u;        // two "0.0" flags
-    // ---- objects: 3 dwords per slot
+    // ---- objects: 3 dwords per slot (in a fused rollout only when an object moved or changed state since the last encode)
+    if (objs_changed)
 #pragma unroll
     for (int k = 0; k < OPL; ++k) {
         const uint32_t w = e.d0[k];
@@ -200,6 +202,7 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
         img32[(IMG_OBJ0 >> 1) + 3 * slot + 2] = q2;
     }
     // ---- cells: the mutable flag (switch_active / block walkable) + the constant 1
+    if (cells_changed)
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const uint32_t fa = ((e.cell[k] >> 5) | (e.cell[k] >> 6)) & 1u;
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(const Params P) {
     if (P.obs) load_desc(P, e.layout, 0, lane, dsc);
     const int64_t env_global = P.env_id_base + env;
     bool cells_dirty = false, objs_dirty = false;
+    bool img_objs = true, img_cells = true;                 // which parts of the LDS image the next encode must rebuild
     CZ_STAMP(1);
 
     const int T = FUSED ? P.T : 1;
@@ -430,7 +434,12 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(const Params P) {
             if (P.trunc) stg<uint8_t>(P.trunc + row * NA, (uint32_t)lane, (uint8_t)o.trunc);
         }
         CZ_STAMP(5);
-        if (P.obs) observe(P, e, cx, lds, dsc, P.obs + row * (size_t)NA * P.F);
+        img_objs |= (dt.touched | dt.moved) != 0;
+        img_cells |= dt.cells != 0;
+        if (P.obs) {
+            observe(P, e, cx, lds, dsc, P.obs + row * (size_t)NA * P.F, img_objs, img_cells);
+            img_objs = false; img_cells = false;
+        }
         CZ_STAMP(6);
     }
     store_env(P, e, cx, rec, cells_dirty, objs_dirty);

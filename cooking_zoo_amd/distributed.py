@@ -76,11 +76,13 @@ def gather_stats_rccl(env, world_size: int, rank: int, broadcast_bytes) -> List[
     on every rank (e.g. via torch.distributed.broadcast_object_list)."""
     L = _native.lib()
     uid = (C.c_uint8 * 128)()
+    payload = None
     if rank == 0:
-        rc = L.cz_comm_unique_id(uid)
-        if rc:
-            _native.check(None, rc)
-    payload = broadcast_bytes(bytes(uid) if rank == 0 else None)
+        # a failure here must reach every rank (they are all waiting in the broadcast): ship b"" instead of raising
+        payload = bytes(uid) if L.cz_comm_unique_id(uid) == 0 else b""
+    payload = broadcast_bytes(payload)
+    if not payload:
+        raise _native.NativeError("rank 0 could not create an RCCL unique id (librccl missing?)")
     uid = (C.c_uint8 * 128).from_buffer_copy(payload)
     _native.check(env._h, L.cz_comm_init(env._h, world_size, rank, uid))
     out = (_native.CzStats * world_size)()

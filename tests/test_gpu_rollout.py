@@ -70,6 +70,11 @@ def stats_from_oracle_run(orc, T, seed):
     ("scheme3", "large_16x16", 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"], "large_16x16"),
     ("scheme3", "coop_test", 1, ["TomatoLettuceSalad"], "example"),
     ("scheme1", "large_16x16", 3, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon"], "large_16x16"),
+    ("scheme3", "large_16x16", 1, ["CucumberOnion"], "large_16x16"),
+    ("scheme1", "large_16x16", 2, ["TomatoLettuceOnionSalad", "MashedCarrotBanana"], "large_16x16"),
+    ("scheme1", "edge_9x8", 1, ["TomatoSalad"], "edge"),
+    ("scheme3", "edge_8x8", 3, ["TomatoSalad", "MashedCarrotBanana", "TomatoLettuceSalad"], "edge"),
+    ("scheme3", "edge_empty", 2, ["TomatoSalad", "no_recipe"], "edge"),
 ])
 def test_step_with_autoreset_matches_oracle(scheme, level, agents, recipes, meta):
     n, T = 96, 75
