@@ -272,6 +272,8 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
             }
         }
     }
+    // the caller keeps the descriptors of chunk 0 across steps (fused rollout): restore them if later chunks replaced them
+    if (P.F > 128 * OBS_PAIRS) load_desc(P, e.layout, 0, cx.lane, dsc);
     __builtin_amdgcn_wave_barrier();
 }
 

@@ -254,3 +254,24 @@ def test_long_fused_rollout_matches_oracle(scheme, agents, level, meta, recipes,
     assert st["episodes"] == int(orc.records[:, soa.W_EPISODE].sum()) + int((orc.records[:, soa.W_STATUS] & 1).sum())
     assert st["env_steps"] > 0.9 * n * T * (ms / (ms + 1.0)) - n
     env.close()
+
+
+def test_fused_trajectory_with_many_descriptor_chunks():
+    """F = 840 needs three descriptor chunks per encode: every step of a fused rollout must still be encoded from
+    chunk 0 onwards (regression test: the chunk-0 descriptors are restored after each encode)."""
+    n, T, seed, A = 48, 12, 5, 4
+    env = make(n, level="large_16x16", meta_file="large_16x16", num_agents=A, max_steps=9,
+               recipes=["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"], num_layouts=6)
+    orc = oracle_for(env)
+    env.reset(return_obs=False)
+    orc.reset()
+    d_obs = env.alloc((T, n, A, env.F), np.float64)
+    env.rollout(T, seed, 0, d_obs)
+    env.sync()
+    obs = d_obs.to_host()
+    lib = orc.oracle.lib
+    for t in range(T):
+        acts = np.array([[lib.czo_action(seed, e, a, t, 5) for a in range(A)] for e in range(n)], dtype=np.int32)
+        oo, _, _, _ = orc.step(acts)
+        assert np.array_equal(bits(obs[t]), bits(oo)), f"obs @ fused step {t}"
+    env.close()
