@@ -32,8 +32,9 @@ constexpr int ENVS_PER_WG = CZ_ENVS_PER_WG;   // one wavefront per env, this man
 constexpr int OBS_PAIRS = 3;       // feature pairs per lane and chunk: 3 x 128 = 384 features per chunk
 constexpr int OBS_CHUNK = 2 * OBS_PAIRS;   // descriptor words held per lane
 
+// (the quotient table `lut` itself is shared by the waves of a workgroup: [0..2W-2] (i-(W-1))/W | [64..64+2H-2] (i-(H-1))/H |
+// [126] 0.0 | [127] 1.0 | [128..255] 0.0)
 struct Lds {
-    double lut[LUT_SIZE];          // [0..2W-2] (i-(W-1))/W | [64..64+2H-2] (i-(H-1))/H | [126] 0.0 | [127] 1.0 | [128..255] 0.0
     uint16_t img[IMG_HALFWORDS];   // objects 6 hw each | cells 4 hw each | agents 8 hw each | the "absent" halfword
     int32_t sub[MAX_AGENTS][16];   // per observer: what to subtract (x8) for each axis code
     uint64_t locs[MAX_NODES * 4];  // recipe evaluation scratch: matched-location bit sets per node (CPL <= 4 words)
@@ -135,14 +136,15 @@ __device__ __forceinline__ uint32_t all_marks(const Params &P, const Env<OPL, CP
     return marks;
 }
 
-// once per kernel: the quotient table and the constant part of the image (cell coordinates)
+// once per kernel and workgroup: the quotient table (thread `tid` of `nthreads`), followed by a workgroup barrier
+__device__ __forceinline__ void init_lut(const Params &P, double *lut, int tid, int nthreads) {
+    for (int i = tid; i < LUT_SIZE; i += nthreads) lut[i] = i < 128 ? ldg<double>(P.lut, (uint32_t)i * 8u) : 0.0;
+}
+
+// once per kernel and env: the constant part of the image (cell coordinates)
 template <int CPL>
 __device__ __forceinline__ void init_lds(const Params &P, const Ctx &cx, Lds &s) {
     const int lane = cx.lane;
-    s.lut[lane] = ldg<double>(P.lut, (uint32_t)lane * 8u);
-    s.lut[64 + lane] = ldg<double>(P.lut, (uint32_t)lane * 8u + 512u);
-    s.lut[128 + lane] = 0.0;
-    s.lut[192 + lane] = 0.0;
     if (lane == 0) s.img[IMG_ZERO] = (uint16_t)(LUT_ABSENT * 8);
     uint32_t *img32 = reinterpret_cast<uint32_t *>(s.img);
     const uint32_t c01 = (uint32_t)((P.W - 1) * 8) | ((uint32_t)((LUT_Y0 + P.H - 1) * 8) << 16);
@@ -179,7 +181,7 @@ __device__ __forceinline__ void load_desc(const Params &P, uint32_t layout, int 
 // keep plain stores (policy in cz_api.hip launch_step).
 template <int OPL, int CPL, int NA>
 __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, Lds &s,
-                                        uint32_t (&dsc)[OBS_CHUNK], double *__restrict__ out /* [A][F] of this env */,
+                                        const double *lut, uint32_t (&dsc)[OBS_CHUNK], double *__restrict__ out /* [A][F] of this env */,
                                         bool objs_changed = true, bool cells_changed = true) {
     uint32_t *img32 = reinterpret_cast<uint32_t *>(s.img);
     const uint32_t dead = (uint32_t)(LUT_ABSENT * 8) * 0x10001u;
@@ -229,7 +231,7 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
     __builtin_amdgcn_wave_barrier();             // one wave owns this LDS region: DS ops of a wave execute in order
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, NA * P.F * 8, 0x00020000);   // the env's [A][F] block
     const bool wt = P.wt != 0;                                                          // wave-uniform
-    const char *lutb = reinterpret_cast<const char *>(s.lut);
+    const char *lutb = reinterpret_cast<const char *>(lut);
     const char *imgb = reinterpret_cast<const char *>(s.img);
     const char *subb = reinterpret_cast<const char *>(s.sub);
     for (int chunk = 0; chunk * 128 * OBS_PAIRS < P.F; ++chunk) {
@@ -371,10 +373,18 @@ __device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, 
 template <int OPL, int CPL, int NA, int SCHEME, bool FUSED>
 __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(const Params P) {
     __shared__ Lds lds_all[ENVS_PER_WG];
+    __shared__ double lut[LUT_SIZE];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = (int)rfl(threadIdx.x >> 6);
     const int env = (int)blockIdx.x * ENVS_PER_WG + wave;
-    if (env >= P.N) return;
+    static_assert(64 * ENVS_PER_WG >= LUT_SIZE, "one table entry per thread");
+    // the quotient table is shared by the workgroup: its load joins the other loads of the prologue
+    const double lutv = threadIdx.x < 128u ? ldg<double>(P.lut, threadIdx.x * 8u) : 0.0;
+    if (env >= P.N) {                                          // (the last workgroup may be partial)
+        if (threadIdx.x < (unsigned)LUT_SIZE) lut[threadIdx.x] = lutv;
+        __syncthreads();
+        return;
+    }
     Lds &lds = lds_all[wave];
     Ctx cx{P.W, P.H, P.D, P.W * P.H, lane};
     CZ_STAMP(0);
@@ -393,6 +403,8 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(const Params P) {
     const int64_t env_global = P.env_id_base + env;
     bool cells_dirty = false, objs_dirty = false;
     bool img_objs = true, img_cells = true;                 // which parts of the LDS image the next encode must rebuild
+    if (threadIdx.x < (unsigned)LUT_SIZE) lut[threadIdx.x] = lutv;
+    __syncthreads();
     CZ_STAMP(1);
 
     const int T = FUSED ? P.T : 1;
@@ -439,7 +451,7 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(const Params P) {
         img_objs |= (dt.touched | dt.moved) != 0;
         img_cells |= dt.cells != 0;
         if (P.obs) {
-            observe(P, e, cx, lds, dsc, P.obs + row * (size_t)NA * P.F, img_objs, img_cells);
+            observe(P, e, cx, lds, lut, dsc, P.obs + row * (size_t)NA * P.F, img_objs, img_cells);
             img_objs = false; img_cells = false;
         }
         CZ_STAMP(6);
@@ -455,6 +467,8 @@ __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin,
                                               const uint32_t *__restrict__ recipe_words, const uint32_t *__restrict__ pool_words,
                                               double *obs_out) {
     __shared__ Lds lds;
+    __shared__ double lut[LUT_SIZE];
+    init_lut(P, lut, (int)threadIdx.x, 64);
     const int i = blockIdx.x;
     const int64_t env = env_begin + i;
     const int lane = (int)threadIdx.x;
@@ -474,7 +488,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin,
     if (obs_out) {
         uint32_t dsc[OBS_CHUNK];
         load_desc(P, e.layout, 0, lane, dsc);
-        observe(P, e, cx, lds, dsc, obs_out + (size_t)i * NA * P.F);
+        observe(P, e, cx, lds, lut, dsc, obs_out + (size_t)i * NA * P.F);
     }
 }
 
@@ -482,6 +496,8 @@ __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin,
 template <int OPL, int CPL, int NA>
 __global__ __launch_bounds__(64) void k_observe(const Params P, int64_t env_begin, double *obs_out) {
     __shared__ Lds lds;
+    __shared__ double lut[LUT_SIZE];
+    init_lut(P, lut, (int)threadIdx.x, 64);
     const int i = blockIdx.x;
     const int lane = (int)threadIdx.x;
     Ctx cx{P.W, P.H, P.D, P.W * P.H, lane};
@@ -490,7 +506,7 @@ __global__ __launch_bounds__(64) void k_observe(const Params P, int64_t env_begi
     load_env(P, e, cx, P.state + (size_t)(env_begin + i) * P.RW);
     uint32_t dsc[OBS_CHUNK];
     load_desc(P, e.layout, 0, lane, dsc);
-    observe(P, e, cx, lds, dsc, obs_out + (size_t)i * NA * P.F);
+    observe(P, e, cx, lds, lut, dsc, obs_out + (size_t)i * NA * P.F);
 }
 
 // launchers exported by each instantiation unit
