@@ -105,7 +105,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = torch = None
-    if world > 1:
+    if world > 1 or os.environ.get("CZ_BENCH_FORCE_DIST"):      # (the variable exercises the multi-rank code path on one GPU)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -202,22 +202,46 @@ def main():
         for b in (d_traj, d_r, d_te, d_tr):
             b.free()
 
-    # episode statistics: RCCL all-gather over xGMI of one cz_stats per rank (the path's only collective)
+    # episode statistics: RCCL all-gather over xGMI of one cz_stats per rank (the path's only collective).
+    # Done twice: through torch.distributed (backend nccl = RCCL) and through the C-ABI's own communicator
+    # (cz_comm_init / cz_stats_allgather); the second runs under a watchdog so that a stuck communicator bring-up on an
+    # unfamiliar node can never cost the timing result.
     stats_all = None
+    rccl_hung = False
     if dist is not None:
         try:
-            def bcast(payload):
-                box = [payload]
-                dist.broadcast_object_list(box, src=0)
-                return box[0]
-            per_rank = czd.gather_stats_rccl(env, world, rank, bcast)
-            stats_all = {"via": "rccl (cz_stats_allgather)", "total": czd.reduce_stats(per_rank)}
-        except Exception as exc:
+            per_rank_t = czd.gather_stats_torch(env.stats(), device=torch.device("cuda", local_rank))
+            stats_all = {"via": "torch.distributed nccl", "total": czd.reduce_stats(per_rank_t)}
+        except Exception as exc:                 # keep the timing result even if the stats exchange fails
+            per_rank_t = None
+            stats_all = {"error": str(exc)}
+        box = {}
+
+        def direct():
             try:
-                per_rank = czd.gather_stats_torch(env.stats(), device=torch.device("cuda", local_rank))
-                stats_all = {"via": f"torch.distributed nccl (direct RCCL path failed: {exc})", "total": czd.reduce_stats(per_rank)}
-            except Exception as exc2:            # keep the timing result even if the stats exchange fails
-                stats_all = {"error": f"{exc}; {exc2}"}
+                torch.cuda.set_device(local_rank)            # the current device is per thread
+                def bcast(payload):
+                    b = [payload]
+                    dist.broadcast_object_list(b, src=0)
+                    return b[0]
+                box["per_rank"] = czd.gather_stats_rccl(env, world, rank, bcast)
+            except Exception as exc:
+                box["error"] = str(exc)
+        th = threading.Thread(target=direct, daemon=True)
+        th.start()
+        th.join(timeout=120.0)
+        flag = torch.tensor([1 if th.is_alive() else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)          # every rank takes the same exit path
+        rccl_hung = bool(flag.item())
+        if th.is_alive():
+            stats_all["cz_stats_allgather"] = "timed out after 120 s (result above is from torch.distributed)"
+        elif "error" in box:
+            stats_all["cz_stats_allgather"] = "failed: " + box["error"]
+        else:
+            same = per_rank_t is not None and box["per_rank"] == per_rank_t
+            stats_all["cz_stats_allgather"] = "ok, identical to the torch.distributed result" if same else "ok"
+            if not same:
+                stats_all["total_direct"] = czd.reduce_stats(box["per_rank"])
 
     if rank == 0:
         b_alg = algorithmic_bytes_per_env_step(env)
@@ -246,7 +270,9 @@ def main():
             line["episode_stats_allgather"] = stats_all
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(env)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    if rccl_hung:
+        os._exit(0)                              # a communicator stuck in bring-up cannot be torn down cleanly
     env.close()
     if dist is not None:
         dist.barrier()

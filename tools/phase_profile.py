@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where does a wave spend its cycles?  Needs the diagnostic build (make -C cooking_zoo_amd/csrc prof) and
 CZ_LIB=cooking_zoo_amd/csrc/libcookingzoo_hip_prof.so.  Prints median s_memtime deltas per phase (shares, not times)."""
+import ctypes as C
 import os
 import sys
 
@@ -27,11 +28,15 @@ d_t = env.alloc((N, 2), np.uint8)
 d_u = env.alloc((N, 2), np.uint8)
 names = ["prologue+loads", "agents", "progress", "rewards/flags", "outputs", "observe", "store"]
 acc = []
-spread, endspread = [], []
+spread, endspread, evt_us = [], [], []
 for it in range(60):
     d_act.from_host(rng.integers(0, 5, size=(N, 2), dtype=np.int32))
+    L.cz_timer_start(h)
     env.step_device(d_act, d_obs, d_rew, d_t, d_u)
-    env.sync()
+    ms = C.c_float()
+    L.cz_timer_stop(h, C.byref(ms))
+    if it >= 10:
+        evt_us.append(ms.value * 1e3)
     s = stamps.to_host().astype(np.int64)
     if it >= 10:
         acc.append(np.diff(s, axis=1))
@@ -42,6 +47,7 @@ tot = np.median((np.concatenate([a.sum(axis=1) for a in acc])))
 life = np.concatenate([a.sum(axis=1) for a in acc])
 print(f"wave lifetime cycles: median {tot:.0f}  p90 {np.percentile(life,90):.0f}  p99 {np.percentile(life,99):.0f}  max-per-launch median {np.median([a.sum(axis=1).max() for a in acc]):.0f}")
 st = np.concatenate([ (a[:,0]*0) for a in acc])
+print(f"event-timed launch (diagnostic build, incl. stamp stores): median {np.median(evt_us):.2f} us")
 print("per-launch: first-start -> last-start", np.median(spread), "cycles; first-start -> last-end", np.median(endspread), "cycles")
 for i, n in enumerate(names):
     print(f"  {n:16s} median {np.median(d[:, i]):8.0f}  mean {d[:, i].mean():8.0f}  ({100 * d[:, i].mean() / d.sum(axis=1).mean():4.1f} %)")
