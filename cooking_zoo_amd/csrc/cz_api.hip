@@ -88,6 +88,9 @@ struct cz_handle_s {
     int32_t *d_actions = nullptr;
     double *d_obs = nullptr, *d_rew = nullptr;
     uint8_t *d_term = nullptr, *d_trunc = nullptr;
+    uint32_t *d_marks = nullptr, *marks_out_next = nullptr;   // (cz_step hands the kernel a marks buffer for one launch)
+    std::vector<uint32_t> last_marks;          // recipe marks after the most recent cz_step (cz_last_marks)
+    char *h_stage = nullptr, *d_stage = nullptr;   // small batches: pinned, device-mapped staging block of cz_step
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // kernel timing
     bool ktime = false;
@@ -100,6 +103,7 @@ struct cz_handle_s {
     void *comm = nullptr;
     int n_ranks = 1, rank = 0;
     int wt_override = -1;          // CZ_WT experiment switch, read once
+    size_t zero_copy_bytes = (size_t)256 << 10;   // cz_step: batches whose buffers fit use the pinned device-mapped block (CZ_ZERO_COPY_BYTES)
     cz_stats *d_gather = nullptr;
     std::string err;
 };
@@ -177,6 +181,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     P.T = 1;
     P.stop = -1;
     if (const char *s = getenv("CZ_WT")) h->wt_override = atoi(s);
+    if (const char *s = getenv("CZ_ZERO_COPY_BYTES")) h->zero_copy_bytes = (size_t)atoll(s);
     if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // honoured by the diagnostic build only
     h->kl = (P.D <= 64 && C <= 64) ? launchers_small() : launchers_large();
     {   // the reward of a step on which no recipe node changed: cooking_env.py:304-307 with zero deltas, same op order
@@ -225,9 +230,10 @@ extern "C" int cz_destroy(cz_handle h) {
         if (f) f(h->comm);
     }
     void *ptrs[] = {h->d_lut, h->d_state, h->d_lay_init, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out,
-                    h->d_actions, h->d_obs, h->d_rew, h->d_term, h->d_trunc, h->d_gather};
+                    h->d_actions, h->d_obs, h->d_rew, h->d_term, h->d_trunc, h->d_gather, h->d_marks};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
     for (hipEvent_t e : h->kev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -455,6 +461,7 @@ extern "C" int cz_step_device(cz_handle h, const int32_t *d_actions, double *d_o
     if (set_device(h)) return 1;
     Params P = h->P;
     P.actions = d_actions; P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
+    P.marks_out = h->marks_out_next; h->marks_out_next = nullptr;
     return launch_step(h, P);
 }
 
@@ -491,20 +498,56 @@ extern "C" int cz_step(cz_handle h, const int32_t *actions, double *obs, double 
     if (!actions || !rewards || !term || !trunc) return fail(h, "cz_step: null buffer");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const size_t NA = (size_t)h->P.N * h->P.A;
+    const size_t ob = NA * h->P.F * 8;
+    // Small batches (the single-env facade): the step is pure latency, so the kernel reads the actions from and writes
+    // its outputs to one pinned, device-mapped host block -- one launch and one synchronisation, no copy commands.
+    const size_t o_act = 0, o_rew = (NA * 4 + 15) & ~(size_t)15, o_term = o_rew + NA * 8, o_trunc = o_term + ((NA + 15) & ~(size_t)15),
+                 o_marks = o_trunc + ((NA + 15) & ~(size_t)15), o_obs = o_marks + (((size_t)h->P.N * 4 + 15) & ~(size_t)15),
+                 total = o_obs + ob;
+    if (total <= h->zero_copy_bytes) {
+        if (!h->h_stage) {
+            HIPCHK(h, hipHostMalloc((void **)&h->h_stage, total, hipHostMallocMapped));
+            HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_stage, h->h_stage, 0));
+        }
+        memcpy(h->h_stage + o_act, actions, NA * 4);
+        h->marks_out_next = (uint32_t *)(h->d_stage + o_marks);
+        if (cz_step_device(h, (const int32_t *)(h->d_stage + o_act), obs ? (double *)(h->d_stage + o_obs) : nullptr,
+                           (double *)(h->d_stage + o_rew), (uint8_t *)(h->d_stage + o_term), (uint8_t *)(h->d_stage + o_trunc)))
+            return 1;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (obs) memcpy(obs, h->h_stage + o_obs, ob);
+        memcpy(rewards, h->h_stage + o_rew, NA * 8);
+        memcpy(term, h->h_stage + o_term, NA);
+        memcpy(trunc, h->h_stage + o_trunc, NA);
+        h->last_marks.assign((const uint32_t *)(h->h_stage + o_marks), (const uint32_t *)(h->h_stage + o_marks) + h->P.N);
+        return 0;
+    }
     if (!h->d_actions) {
         HIPCHK(h, hipMalloc(&h->d_actions, NA * 4));
         HIPCHK(h, hipMalloc(&h->d_rew, NA * 8));
         HIPCHK(h, hipMalloc(&h->d_term, NA));
         HIPCHK(h, hipMalloc(&h->d_trunc, NA));
+        HIPCHK(h, hipMalloc(&h->d_marks, (size_t)h->P.N * 4));
     }
-    if (obs && !h->d_obs) HIPCHK(h, hipMalloc(&h->d_obs, NA * h->P.F * 8));
+    if (obs && !h->d_obs) HIPCHK(h, hipMalloc(&h->d_obs, ob));
     HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, NA * 4, hipMemcpyHostToDevice, h->stream));
+    h->marks_out_next = h->d_marks;
+    h->last_marks.resize((size_t)h->P.N);
     if (cz_step_device(h, h->d_actions, obs ? h->d_obs : nullptr, h->d_rew, h->d_term, h->d_trunc)) return 1;
-    if (obs) HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, NA * h->P.F * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->last_marks.data(), h->d_marks, (size_t)h->P.N * 4, hipMemcpyDeviceToHost, h->stream));
+    if (obs) HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, ob, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(rewards, h->d_rew, NA * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(term, h->d_term, NA, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(trunc, h->d_trunc, NA, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int cz_last_marks(cz_handle h, uint32_t *out) {
+    if (ready(h)) return 1;
+    if (!out) return fail(h, "cz_last_marks: null buffer");
+    if (h->last_marks.size() != (size_t)h->P.N) return fail(h, "cz_last_marks: no cz_step has run on this handle yet");
+    memcpy(out, h->last_marks.data(), (size_t)h->P.N * 4);
     return 0;
 }
 

@@ -58,6 +58,7 @@ struct Params {
     double *obs;                   // [N][A][F] / [T][N][A][F] / nullptr
     double *rewards;               // [N][A] / [T][N][A] / nullptr
     uint8_t *term, *trunc;         // likewise
+    uint32_t *marks_out;           // [N] recipe-node marks after the step (host-pointer cz_step only), or nullptr
     uint32_t *stat_u;              // [N][SU_WORDS]
     double *stat_f;                // [N][SF_WORDS]
     int64_t env_id_base;

@@ -447,6 +447,7 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(const Params P) {
             if (P.term) stg<uint8_t>(P.term + row * NA, (uint32_t)lane, (uint8_t)o.term);
             if (P.trunc) stg<uint8_t>(P.trunc + row * NA, (uint32_t)lane, (uint8_t)o.trunc);
         }
+        if (!FUSED && P.marks_out && lane == 0) P.marks_out[env] = e.marks;     // infos["recipe_done"] of the host API
         CZ_STAMP(5);
         img_objs |= (dt.touched | dt.moved) != 0;
         img_cells |= dt.cells != 0;

@@ -168,7 +168,7 @@ class CookingEnvironment:
             raise ValueError(f"actions must be in [0, {n}) for {self.action_scheme}")
         obs, rew, term, trunc = self._vec.step(np.asarray([acts], dtype=np.int32))
         self.t += 1
-        self._refresh_marks()
+        self._set_marks(int(self._vec.last_marks()[0]))
         truncated = bool(trunc[0, 0])
         if truncated:
             self.termination_info = f"Terminating because {self.max_steps} timesteps passed"
@@ -194,7 +194,9 @@ class CookingEnvironment:
         return self._vec.observe()[0, self.possible_agents.index(agent)].copy()
 
     def _refresh_marks(self):
-        marks = int(self._vec.get_state()[0, soa.W_MARKS])
+        self._set_marks(int(self._vec.get_state()[0, soa.W_MARKS]))
+
+    def _set_marks(self, marks):
         for r, g in enumerate(self.recipe_graphs):
             g.set_marks((marks >> (8 * r)) & 0xFF)
 

@@ -185,6 +185,12 @@ class CookingVecEnv:
         _native.check(self._h, _native.lib().cz_step(self._h, _ptr(acts), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc)))
         return obs, rew, term, trunc
 
+    def last_marks(self):
+        """Recipe-node marks (uint32 [N], bit 8r+j) after the most recent host-array `step`."""
+        marks = np.empty(self.num_envs, dtype=np.uint32)
+        _native.check(self._h, _native.lib().cz_last_marks(self._h, _ptr(marks)))
+        return marks
+
     def observe(self, env_begin=0, env_count=None):
         n = self.num_envs if env_count is None else int(env_count)
         obs = np.empty((n, self.num_agents, self.F), dtype=np.float64)

@@ -111,6 +111,11 @@ int cz_observe(cz_handle h, int64_t env_begin, int64_t env_count, double *obs);
 int cz_step(cz_handle h, const int32_t *actions, double *obs, double *rewards, uint8_t *terminations,
             uint8_t *truncations);
 
+/* Recipe-node marks (record word 1: bit 8r+j = node j of the env's r-th recipe is met, bit 8r = recipe r complete) of
+ * every env after the most recent cz_step: what compute_infos reports as `recipe_done` (cooking_env.py:317-331).
+ * uint32 [N].  Fails if cz_step has not run on this handle. */
+int cz_last_marks(cz_handle h, uint32_t *marks);
+
 /* Device-pointer form, asynchronous on the handle's stream (d_obs may be NULL: encode skipped). */
 int cz_step_device(cz_handle h, const int32_t *d_actions, double *d_obs, double *d_rewards,
                    uint8_t *d_terminations, uint8_t *d_truncations);

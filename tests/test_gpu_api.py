@@ -77,3 +77,22 @@ def test_unsupported_modes_fail_loudly():
         parallel_env(action_scheme="scheme2", **kw)
     with pytest.raises(NotImplementedError):
         parallel_env(action_scheme="scheme3", agent_despawn_rate=0.1, **kw)
+
+
+def test_last_marks_matches_state_on_both_host_paths():
+    """cz_last_marks (what the facade reports as recipe_done) == record word 1, on the zero-copy small-batch path of
+    cz_step and on the staged-copy path."""
+    from cooking_zoo_amd import soa
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    for n in (3, 700):                      # 3 envs: pinned device-mapped block; 700 envs x 2 x 278 x 8 B > 256 KiB: staged copies
+        env = CookingVecEnv(n, "coop_test", "example", 2, 30, ["TomatoLettuceSalad", "CarrotBanana"],
+                            action_scheme="scheme3", num_layouts=4, auto_reset=True)
+        env.reset()
+        with pytest.raises(Exception):
+            env.last_marks()                # no step yet
+        rng = np.random.default_rng(n)
+        for t in range(40):
+            obs, rew, term, trunc = env.step(rng.integers(0, 5, size=(n, 2)))
+            assert np.array_equal(env.last_marks(), env.get_state()[:, soa.W_MARKS]), (n, t)
+        assert np.array_equal(bits(obs), bits(env.observe()))
+        env.close()
