@@ -376,15 +376,14 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(const Params P) {
     __shared__ double lut[LUT_SIZE];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = (int)rfl(threadIdx.x >> 6);
-    const int env = (int)blockIdx.x * ENVS_PER_WG + wave;
+    // (the last workgroup may be partial: its spare waves shadow the last env up to the barrier, then leave)
+    const int env_raw = (int)blockIdx.x * ENVS_PER_WG + wave;
+    const int env = min(env_raw, P.N - 1);
     static_assert(64 * ENVS_PER_WG >= LUT_SIZE, "one table entry per thread");
-    // the quotient table is shared by the workgroup: its load joins the other loads of the prologue
-    const double lutv = threadIdx.x < 128u ? ldg<double>(P.lut, threadIdx.x * 8u) : 0.0;
-    if (env >= P.N) {                                          // (the last workgroup may be partial)
-        if (threadIdx.x < (unsigned)LUT_SIZE) lut[threadIdx.x] = lutv;
-        __syncthreads();
-        return;
-    }
+    // the quotient table is shared by the workgroup: its load joins the other loads of the prologue (no branch here:
+    // a branch would split the kernel-argument fetch into several dependent round trips)
+    double lutv = ldg<double>(P.lut, min(threadIdx.x, 127u) * 8u);
+    lutv = threadIdx.x < 128u ? lutv : 0.0;
     Lds &lds = lds_all[wave];
     Ctx cx{P.W, P.H, P.D, P.W * P.H, lane};
     CZ_STAMP(0);
@@ -405,6 +404,7 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(const Params P) {
     bool img_objs = true, img_cells = true;                 // which parts of the LDS image the next encode must rebuild
     if (threadIdx.x < (unsigned)LUT_SIZE) lut[threadIdx.x] = lutv;
     __syncthreads();
+    if (env_raw >= P.N) return;
     CZ_STAMP(1);
 
     const int T = FUSED ? P.T : 1;
