@@ -8,6 +8,8 @@ Same constructor kwargs, method names, dict keys and return shapes as the refere
     obs, infos = env.reset()
     obs, rewards, terminations, truncations, infos = env.step({"player_0": a0, "player_1": a1})
 
+`env(...)` returns the agent-iterator (AEC) view of the same environment (AECCookingEnvironment below).
+
 What is deliberately not offered ("out of scope" / "next"): the "symbolic" and "full" observation modes,
 pygame rendering, agent despawn/respawn rates > 0 and scheme2 (which raises AttributeError in the reference itself).
 For many envs at once use cooking_zoo_amd.vec_env.CookingVecEnv -- this facade is the num_envs = 1 case of it.
@@ -211,9 +213,126 @@ class CookingEnvironment:
         self._vec.close()
 
 
-def env(**kwargs):
-    """The reference's `env()` returns the AEC environment; the accelerated path only offers the parallel API."""
-    raise NotImplementedError("the AEC (agent-iterator) API is not offered; use parallel_env(...)")
+class AECCookingEnvironment:
+    """Agent-iterator (AEC) view of the same environment: what the reference's raw `CookingEnvironment` offers through
+    `step(action)` / `last()` / `agent_iter()` (cooking_env.py:215-241; gym id cookingZooEnv-v0).
+
+    Agents act in turn; the world advances once the last agent of the round has chosen (one batched device step).
+    Bookkeeping follows the reference call by call (tests/golden/aec_traces.json), including two things a PettingZoo
+    user would not expect: rewards are zeroed for everybody on every sub-step, and after each call the cumulative
+    reward that is cleared is the LAST agent's (the loop variable of cooking_env.py:229 shadows the acting agent), so
+    every other agent's `last()` reward keeps growing over the episode.
+    """
+
+    metadata = CookingEnvironment.metadata
+
+    def __init__(self, *args, **kwargs):
+        self._core = CookingEnvironment(*args, **kwargs)
+        self.possible_agents = self._core.possible_agents[:]
+        self.agents = self.possible_agents[:]
+        self.observation_spaces, self.action_spaces = self._core.observation_spaces, self._core.action_spaces
+        self.agent_selection = None
+        self._pending = []
+        self._turn = 0
+        self._ended_by_truncation = False
+        self.rewards, self._cumulative_rewards, self.terminations, self.truncations, self.infos = {}, {}, {}, {}, {}
+        self._obs = {}
+
+    # -- plumbing shared with the parallel facade
+    unwrapped = property(lambda self: self)
+    num_agents = property(lambda self: len(self.agents))
+    max_num_agents = property(lambda self: len(self.possible_agents))
+    world = property(lambda self: self._core.world)
+    t = property(lambda self: self._core.t)
+    recipe_graphs = property(lambda self: self._core.recipe_graphs)
+
+    def observation_space(self, agent):
+        return self.observation_spaces[agent]
+
+    def action_space(self, agent):
+        return self.action_spaces[agent]
+
+    def reset(self, seed=None, return_info=False, options=None):
+        """cooking_env.py:178-210"""
+        self._obs, _ = self._core.reset(seed=seed, options=options)
+        self.agents = self.possible_agents[:]
+        self._turn = 0
+        self.agent_selection = self.agents[0]
+        self._pending = []
+        self._ended_by_truncation = False
+        self.rewards = {a: 0 for a in self.agents}
+        self._cumulative_rewards = {a: 0 for a in self.agents}
+        self.terminations = {a: False for a in self.agents}
+        self.truncations = {a: False for a in self.agents}
+        self.infos = {a: {} for a in self.agents}
+
+    def observe(self, agent):
+        """The feature vector of the current world (it only changes when a round completes)."""
+        return self._obs[agent].copy()
+
+    def last(self, observe=True):
+        a = self.agent_selection
+        return (self.observe(a) if observe else None, self._cumulative_rewards[a], self.terminations[a],
+                self.truncations[a], self.infos[a])
+
+    def agent_iter(self, max_iter=2 ** 63):
+        n = 0
+        while self.agents and n < max_iter:
+            yield self.agent_selection
+            n += 1
+
+    def step(self, action):
+        """cooking_env.py:215-241"""
+        if self.agent_selection is None:
+            raise RuntimeError("reset() must be called before step()")
+        if action is None:
+            # a finished agent is acknowledged with None.  After a truncation nobody is active any more, which empties
+            # the agent list; after a termination the reference changes nothing (SURVEY A.12(5)) and neither does this.
+            if self._ended_by_truncation:
+                self.agents = []
+            return
+        me = self.agent_selection
+        if self.terminations[me] or self.truncations[me]:
+            raise ValueError("when an agent is terminated or truncated, the only valid action is None")
+        self._pending.append(int(action))
+        for a in self.agents:
+            self.rewards[a] = 0
+        tail = self.agents[-1]                       # whose cumulative reward the reference clears (see class docstring)
+        if me == self.agents[-1]:
+            actions, self._pending = self._pending, []
+            obs, rew, term, trunc, infos = self._core.step(dict(zip(self.possible_agents, actions)))
+            self._obs = obs
+            self.rewards, self.terminations, self.truncations, self.infos = rew, term, trunc, infos
+            for a in self.possible_agents:
+                self._cumulative_rewards[a] += rew[a]
+            self._ended_by_truncation = any(trunc.values())
+            self._turn = 0                            # a fresh selector: the next round starts with the first agent
+            for a in self.agents:
+                if term[a] or trunc[a]:
+                    self.agent_selection = a
+                    self._cumulative_rewards[tail] = 0
+                    return
+            self.agent_selection = self.agents[0]
+        else:
+            self.agent_selection = self.agents[self._turn + 1] if self._turn + 1 < len(self.agents) else self.agents[0]
+            self._turn += 1
+        self._cumulative_rewards[tail] = 0
+
+    def render(self, **kwargs):
+        return self._core.render(**kwargs)
+
+    def close(self):
+        self._core.close()
+
+
+def env(level, meta_file, num_agents, max_steps, recipes, agent_visualization=None, obs_spaces=None,
+        end_condition_all_dishes=False, action_scheme="scheme1", render=False, reward_scheme=None,
+        agent_respawn_rate=0.0, grace_period=20, agent_despawn_rate=0.0, device_id=0):
+    """The AEC environment (cooking_env.py:26-43, without PettingZoo's stdout-capture / order-enforcing wrappers)."""
+    return AECCookingEnvironment(level, meta_file, num_agents, max_steps, recipes, agent_visualization, obs_spaces,
+                                 end_condition_all_dishes=end_condition_all_dishes, action_scheme=action_scheme,
+                                 render=render, reward_scheme=reward_scheme, agent_respawn_rate=agent_respawn_rate,
+                                 grace_period=grace_period, agent_despawn_rate=agent_despawn_rate, device_id=device_id)
 
 
 def parallel_env(level, meta_file, num_agents, max_steps, recipes, agent_visualization=None, obs_spaces=None,

@@ -96,3 +96,55 @@ def test_last_marks_matches_state_on_both_host_paths():
             assert np.array_equal(env.last_marks(), env.get_state()[:, soa.W_MARKS]), (n, t)
         assert np.array_equal(bits(obs), bits(env.observe()))
         env.close()
+
+
+AEC_TRACES = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "aec_traces.json")))
+
+
+@pytest.mark.parametrize("case", AEC_TRACES, ids=lambda c: f"{c['kwargs']['level']}-A{c['kwargs']['num_agents']}-{c['kwargs']['action_scheme']}")
+def test_aec_env_matches_reference_trace(case):
+    """The agent-iterator API (cooking_env.py:215-241) call by call: selected agent, last() tuple, and the bookkeeping
+    dicts after every step(action | None), through a truncation (agent list empties) and a termination (no progress)."""
+    from cooking_zoo_amd.environment.cooking_env import env as aec_env
+    random.seed(case["seed"])
+    np.random.seed(case["seed"])
+    e = aec_env(**case["kwargs"])
+    e.reset()
+    assert e.agent_selection == case["after_reset"]["agent_selection"] and e.agents == case["after_reset"]["agents"]
+    for k, call in enumerate(case["calls"]):
+        assert e.agents, k
+        assert e.agent_selection == call["agent"], k
+        obs, cum, term, trunc, info = e.last()
+        ref = call["last"]
+        assert np.array_equal(bits(obs), bits(np.array(ref["obs"]))), k
+        assert np.array_equal(bits(np.float64(cum)), bits(np.float64(ref["reward"]))), (k, cum, ref["reward"])
+        assert (term, trunc) == (ref["termination"], ref["truncation"]), k
+        assert set(info) == set(ref["info"]) and all(
+            (list(info[q]) if q == "goal_vector" else info[q]) == ref["info"][q] for q in info), k
+        e.step(call["action"])
+        after = call["after"]
+        assert e.agents == after["agents"], k
+        if after["agents"]:
+            assert e.agent_selection == after["agent_selection"], k
+        for name, want in (("rewards", after["rewards"]), ("_cumulative_rewards", after["cumulative"])):
+            got = getattr(e, name)
+            assert set(got) == set(want), (k, name)
+            for a in want:
+                assert np.array_equal(bits(np.float64(got[a])), bits(np.float64(want[a]))), (k, name, a, got[a], want[a])
+        assert {a: bool(v) for a, v in e.terminations.items()} == after["terminations"], k
+        assert {a: bool(v) for a, v in e.truncations.items()} == after["truncations"], k
+        assert e.t == after["t"], k
+    # agent_iter drives the same loop
+    e.reset()
+    seen = []
+    for agent in e.agent_iter(max_iter=2 * len(e.possible_agents)):
+        seen.append(agent)
+        e.step(0)
+    assert seen == (e.possible_agents * 2)[:len(seen)] and len(seen) == 2 * len(e.possible_agents)
+    with pytest.raises(ValueError):
+        dead = aec_env(**{**case["kwargs"], "max_steps": 1})
+        dead.reset()
+        for _ in dead.possible_agents:
+            dead.step(0)
+        dead.step(0)                                  # truncated: only None is valid now
+    e.close()

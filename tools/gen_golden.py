@@ -585,6 +585,7 @@ def main():
                 [(210, "bumper", 100), (211, "uniform", 100)], args.out))
     sets["api_traces"] = lambda: api_traces(args.out)
     sets["layouts_ref"] = lambda: layout_draws(args.out)
+    sets["aec_traces"] = lambda: aec_traces(args.out)
     for name, fn in sets.items():
         if args.only and args.only != name:
             continue
@@ -642,6 +643,68 @@ def api_traces(out_dir):
     with open(path, "w") as f:
         json.dump(out, f)
     print(f"[golden] api_traces: {len(out)} cases, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def aec_traces(out_dir):
+    """The raw AEC environment (cooking_env.py:215-241 step, :178-210 reset; gym id cookingZooEnv-v0) driven the
+    agent_iter way: before every call the selected agent and its last() tuple, after it the bookkeeping dicts.  A dead
+    agent is stepped with None (truncation empties the agent list, termination makes no progress -- SURVEY A.12(5)).
+    The turn-taking helpers (agent_selector, AECEnv.last) are tools/refshim's paraphrase of pettingzoo's."""
+    from cooking_zoo.environment.cooking_env import CookingEnvironment
+    cases = [
+        dict(seed=1, kwargs=dict(level="coop_test", meta_file="example", num_agents=1, max_steps=400,
+                                 recipes=["TomatoLettuceSalad"], obs_spaces=["feature_vector"],
+                                 end_condition_all_dishes=True, action_scheme="scheme3"),
+             actions=[[int(c)] for c in "312442214141113331242131124444"]),
+        dict(seed=7, kwargs=dict(level="coop_test", meta_file="example", num_agents=2, max_steps=5,
+                                 recipes=["TomatoLettuceSalad", "CarrotBanana"], obs_spaces=["feature_vector", "feature_vector"],
+                                 action_scheme="scheme3"),
+             actions=[[1, 2], [3, 4], [0, 1], [2, 2], [4, 3], [1, 1]]),
+        dict(seed=3, kwargs=dict(level="coexistence_test", meta_file="example", num_agents=2, max_steps=12,
+                                 recipes=["TomatoSalad", "CarrotBanana"], obs_spaces=["feature_vector", "feature_vector"],
+                                 action_scheme="scheme1",
+                                 reward_scheme={"recipe_reward": 10, "max_time_penalty": -3, "recipe_penalty": -7,
+                                                "recipe_node_reward": 1}),
+             actions=[[int(a), int(b)] for a, b in np.random.default_rng(9).integers(0, 8, size=(14, 2))]),
+    ]
+    out = []
+    for case in cases:
+        random.seed(case["seed"])
+        np.random.seed(case["seed"])
+        env = CookingEnvironment(**case["kwargs"])
+        env.reset()
+        names = list(env.possible_agents)
+        cursor = {a: 0 for a in names}
+        rec = {"seed": case["seed"], "kwargs": case["kwargs"], "possible_agents": names,
+               "after_reset": {"agent_selection": env.agent_selection, "agents": list(env.agents)}, "calls": []}
+        dead_calls = 0
+        while env.agents and dead_calls < 3:
+            agent = env.agent_selection
+            obs, cum, term, trunc, info = env.last()
+            if term or trunc:
+                action = None
+                dead_calls += 1
+            else:
+                idx = names.index(agent)
+                if cursor[agent] >= len(case["actions"]):
+                    break
+                action = case["actions"][cursor[agent]][idx]
+                cursor[agent] += 1
+            env.step(action)
+            rec["calls"].append({
+                "agent": agent, "action": action,
+                "last": {"obs": np.asarray(obs).tolist(), "reward": float(cum), "termination": bool(term), "truncation": bool(trunc),
+                         "info": {kk: (vv.tolist() if hasattr(vv, "tolist") else vv) for kk, vv in info.items()}},
+                "after": {"agent_selection": env.agent_selection if env.agents else None, "agents": list(env.agents),
+                          "rewards": {k: float(v) for k, v in env.rewards.items()},
+                          "cumulative": {k: float(v) for k, v in env._cumulative_rewards.items()},
+                          "terminations": {k: bool(v) for k, v in env.terminations.items()},
+                          "truncations": {k: bool(v) for k, v in env.truncations.items()}, "t": int(env.t)}})
+        out.append(rec)
+    path = os.path.join(out_dir, "aec_traces.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print(f"[golden] aec_traces: {len(out)} cases, {sum(len(r['calls']) for r in out)} calls, {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 def layout_draws(out_dir):
