@@ -559,35 +559,43 @@ struct Ops {
         //  * inside a plate: free iff it is the last appended (seq == count-1)
         //  * held directly by an agent: untouched
         if (dt.interacted) {
-            OM held = OM::zero();
-#pragma unroll
-            for (int a = 0; a < NA; ++a) {
-                const int hs = (int)(rdl(e.agw, a) >> 24) - 1;
-                if (hs >= 0) held.set(hs);
-            }
-            // every object lying directly on a static is the last (only) item of that static's content ...
-#pragma unroll
-            for (int k = 0; k < OPL; ++k) {
-                bool on_static = (e.d0[k] & D_ALIVE) && (e.d1[k] & 0xFFu) == 0 && !((held.w[k] >> cx.lane) & 1);
-                if (on_static) e.d0[k] |= D_FREE;
-            }
-            // ... except on a Cutboard that carries a Bread and its clone (the only way a static gets two items,
-            // world_objects.py:738-745): both are chopped Breads lying directly on the same cell
-            OM twins = oballot(e, [](uint32_t a, uint32_t b) {
+            // The pass over the statics can only change something if an object lying directly on a static is not free, or
+            // if a Bread and its clone may share a Cutboard; both are rare, so test for them first (exact for any state).
+            const OM unfree = oballot(e, [](uint32_t a, uint32_t b) { return (a & (D_ALIVE | D_FREE)) == D_ALIVE && (b & 0xFFu) == 0; });
+            const OM breads = oballot(e, [](uint32_t a, uint32_t b) {
                 return (a & (D_ALIVE | D_CHOPPED | 0xFF0000u)) == (D_ALIVE | D_CHOPPED | (BREAD << 16)) && (b & 0xFFu) == 0;
-            }).andnot(held);
-            if (twins.count() > 1) {
-                OM it = twins;
-                while (it.any()) {
-                    const int s = it.first();
-                    const uint32_t xy = slot_d0(e, s) & 0xFFFFu;
-                    OM content = direct_at(e, xy).andnot(held);
-                    it = it.andnot(content);
-                    if (content.count() > 1) {
-                        const int last = content.last();
+            });
+            if (unfree.any() || breads.count() > 1) {
+                OM held = OM::zero();
 #pragma unroll
-                        for (int k = 0; k < OPL; ++k)
-                            if (((content.w[k] >> cx.lane) & 1) && (cx.lane + 64 * k) != last) e.d0[k] &= ~D_FREE;
+                for (int a = 0; a < NA; ++a) {
+                    const int hs = (int)(rdl(e.agw, a) >> 24) - 1;
+                    if (hs >= 0) held.set(hs);
+                }
+                // every object lying directly on a static is the last (only) item of that static's content ...
+#pragma unroll
+                for (int k = 0; k < OPL; ++k) {
+                    bool on_static = (e.d0[k] & D_ALIVE) && (e.d1[k] & 0xFFu) == 0 && !((held.w[k] >> cx.lane) & 1);
+                    if (on_static) e.d0[k] |= D_FREE;
+                }
+                // ... except on a Cutboard that carries a Bread and its clone (the only way a static gets two items,
+                // world_objects.py:738-745): both are chopped Breads lying directly on the same cell
+                OM twins = oballot(e, [](uint32_t a, uint32_t b) {
+                    return (a & (D_ALIVE | D_CHOPPED | 0xFF0000u)) == (D_ALIVE | D_CHOPPED | (BREAD << 16)) && (b & 0xFFu) == 0;
+                }).andnot(held);
+                if (twins.count() > 1) {
+                    OM it = twins;
+                    while (it.any()) {
+                        const int s = it.first();
+                        const uint32_t xy = slot_d0(e, s) & 0xFFFFu;
+                        OM content = direct_at(e, xy).andnot(held);
+                        it = it.andnot(content);
+                        if (content.count() > 1) {
+                            const int last = content.last();
+#pragma unroll
+                            for (int k = 0; k < OPL; ++k)
+                                if (((content.w[k] >> cx.lane) & 1) && (cx.lane + 64 * k) != last) e.d0[k] &= ~D_FREE;
+                        }
                     }
                 }
             }
