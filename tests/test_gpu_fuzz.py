@@ -1,0 +1,75 @@
+"""GPU: randomised differential test of the HIP path against the oracle -- random level / scheme / agent count / recipe
+assignment / horizon / reward scheme / end condition per case, a fused rollout of T steps over the counter-based action
+stream, then final records, last observation and statistics must agree bit for bit.
+
+Default: a handful of cases (seconds).  CZ_FUZZ_CASES=N widens it for one-off soak runs (200 cases are about
+37 M env-steps)."""
+import os
+
+import numpy as np
+import pytest
+
+from cooking_zoo_amd import soa
+from test_gpu_rollout import bits, make, oracle_for, strip
+
+pytestmark = pytest.mark.gpu
+
+LEVELS = [("coop_test", "example", 2), ("coexistence_test", "example", 2), ("switch_test", "example", 2),
+          ("large_16x16", "large_16x16", 4), ("crowded_6x5", "crowded_6x5", 4), ("edge_8x8", "edge", 3),
+          ("edge_9x8", "edge", 3), ("edge_empty", "edge", 3)]
+BOOK = ["TomatoSalad", "TomatoLettuceSalad", "CarrotBanana", "MashedCarrotBanana", "CucumberOnion", "AppleWatermelon",
+        "TomatoLettuceOnionSalad", "no_recipe"]
+N_CASES = int(os.environ.get("CZ_FUZZ_CASES", "6"))
+
+
+def draw_case(i):
+    rng = np.random.default_rng(1000 + i)
+    level, meta, max_agents = LEVELS[int(rng.integers(len(LEVELS)))]
+    agents = int(rng.integers(1, max_agents + 1))
+    n_rec = int(rng.integers(agents, 5))
+    recipes = [BOOK[int(k)] for k in rng.integers(len(BOOK), size=n_rec)]
+    reward = None
+    if rng.random() < 0.5:
+        reward = {"recipe_reward": float(rng.integers(1, 30)), "max_time_penalty": float(-rng.integers(0, 9)),
+                  "recipe_penalty": float(-rng.integers(0, 50)), "recipe_node_reward": float(rng.integers(0, 4))}
+    return dict(level=level, meta_file=meta, num_agents=agents, recipes=recipes,
+                action_scheme="scheme3" if rng.random() < 0.6 else "scheme1", max_steps=int(rng.integers(5, 260)),
+                end_condition_all_dishes=bool(rng.random() < 0.3), reward_scheme=reward,
+                num_layouts=int(rng.integers(1, 40)), layout_seed=int(rng.integers(1 << 20))), int(rng.integers(1 << 30))
+
+
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_random_configuration_matches_oracle(i):
+    kw, seed = draw_case(i)
+    n, T = 384, 480
+    env = make(n, **kw)
+    orc = oracle_for(env)
+    env.reset(return_obs=False)
+    orc.reset()
+    A = kw["num_agents"]
+    chunk = T // 3
+    d_rew = env.alloc((chunk, n, A), np.float64)
+    d_term = env.alloc((chunk, n, A), np.uint8)
+    d_trunc = env.alloc((chunk, n, A), np.uint8)
+    ctx = f"case {i}: {kw}"
+    for t0 in range(0, T, chunk):                   # three launches: the state round-trips through HBM in between
+        env.rollout(chunk, seed, t0, None, d_rew, d_term, d_trunc)
+        env.sync()
+        oo, ro, to, uo = orc.rollout(chunk, seed, t0)
+        assert np.array_equal(strip(env.get_state()), orc.records), ctx
+        assert np.array_equal(bits(d_rew.to_host()[-1]), bits(ro)), ctx
+        assert np.array_equal(d_term.to_host()[-1], to) and np.array_equal(d_trunc.to_host()[-1], uo), ctx
+        assert np.array_equal(bits(env.observe()), bits(oo)), ctx
+    # ... and on from there with one launch per step and actions from the host (the other kernel variant)
+    rng = np.random.default_rng(seed)
+    n_act = 5 if kw["action_scheme"] == "scheme3" else 8
+    for t in range(25):
+        acts = rng.integers(0, n_act, size=(n, A), dtype=np.int32)
+        o, r, te, tr = env.step(acts)
+        oo, ro, to, uo = orc.step(acts)
+        assert np.array_equal(bits(o), bits(oo)) and np.array_equal(bits(r), bits(ro)), (ctx, t)
+        assert np.array_equal(te, to) and np.array_equal(tr, uo), (ctx, t)
+    assert np.array_equal(strip(env.get_state()), orc.records), ctx
+    st = env.stats()
+    assert st["episodes"] == int(orc.records[:, soa.W_EPISODE].sum()) + int((orc.records[:, soa.W_STATUS] & 1).sum()), ctx
+    env.close()
