@@ -444,7 +444,10 @@ struct Ops {
     static __device__ __forceinline__ void perform_agent_actions(E &e, const Ctx &cx, uint32_t act, Dirty &dt) {
         const uint32_t W = (uint32_t)cx.W, H = (uint32_t)cx.H;
         uint32_t x = e.agw & 0xFFu, y = (e.agw >> 8) & 0xFFu, o = (e.agw >> 16) & 0xFFu;
-        act &= 7u;
+        // a negative action = the agent is despawned: it is not in the list world_step acts on (cooking_world.py:105-108:
+        // no turn, no move, no part in the collision filter) but keeps its place in the world
+        const bool live = (int32_t)act >= 0;
+        act = live ? (act & 7u) : 0u;
         if (act - 1u < 4u) o = act;                                         // change_orientation before any filtering
         uint32_t tx = x + ((DX_TABLE >> (2u * act)) & 3u) - 1u, ty = y + ((DY_TABLE >> (2u * act)) & 3u) - 1u;
         // check_inbounds (0 and 5 pass; 6 and 7 aim at the own cell, always inside); negative wraps to huge
@@ -456,12 +459,12 @@ struct Ops {
         const bool wk = walkable(tcv);
         // check_collisions: an agent is cancelled iff its end cell equals another agent's end cell and its own
         // target was walkable.  count how many agents (including itself) end on this lane's end cell
-        const uint32_t exy = wk ? (tx | (ty << 8)) : (x | (y << 8));
+        const uint32_t exy = !live ? (0xFFFF0000u | (uint32_t)cx.lane) : wk ? (tx | (ty << 8)) : (x | (y << 8));
         uint32_t cnt = 0;
 #pragma unroll
         for (int b = 0; b < NA; ++b) cnt += (exy == rdl(exy, b)) ? 1u : 0u;
         if (NA > 1 && cnt > 1u && wk && act != 0u) { act = 0; tx = x; ty = y; c = own; tcv = ocv; }   // now "walks" onto its own cell
-        const bool is_agent = cx.lane < NA;
+        const bool is_agent = cx.lane < NA && live;
         if (is_agent) e.agw = (e.agw & 0xFF00FFFFu) | (o << 16);              // lanes >= NA stay 0 (unused agent words)
         // ---- execution.  The reference resolves agents one after the other (action_scheme3.py:15-16), but a walking
         // agent only changes its own position, the position of what it carries and Switch bits, while an interacting

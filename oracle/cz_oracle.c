@@ -459,7 +459,7 @@ static void check_inbounds(const World *w, const int *actions, int *out)
 {
     for (int a = 0; a < w->A; ++a) {
         int act = actions[a];
-        if (act == 0 || act == 5) { out[a] = act; continue; }
+        if (act < 0 || act == 0 || act == 5) { out[a] = act; continue; }     /* act < 0: not in the active list */
         int tx, ty;
         target(w->ag[a].x, w->ag[a].y, act, &tx, &ty);
         if (tx > w->W - 1 || tx < 0) act = 0;
@@ -474,6 +474,7 @@ static void check_collisions(const World *w, const int *actions, int *out)
     int ex[CZO_MAX_AGENTS], ey[CZO_MAX_AGENTS], wk[CZO_MAX_AGENTS];
     for (int a = 0; a < w->A; ++a) {
         int tx, ty;
+        if (actions[a] < 0) continue;
         target(w->ag[a].x, w->ag[a].y, actions[a], &tx, &ty);
         wk[a] = walkable(w, tx, ty);
         ex[a] = wk[a] ? tx : w->ag[a].x;
@@ -481,7 +482,9 @@ static void check_collisions(const World *w, const int *actions, int *out)
     }
     for (int a = 0; a < w->A; ++a) {
         int clash = 0;
-        for (int b = 0; b < w->A; ++b) if (b != a && ex[b] == ex[a] && ey[b] == ey[a]) clash = 1;
+        if (actions[a] < 0) { out[a] = -1; continue; }
+        /* only the agents that act take part (world_step passes compute_active_agents(), cooking_world.py:105,108) */
+        for (int b = 0; b < w->A; ++b) if (b != a && actions[b] >= 0 && ex[b] == ex[a] && ey[b] == ey[a]) clash = 1;
         out[a] = (clash && wk[a]) ? 0 : actions[a];
     }
 }
@@ -491,6 +494,8 @@ static void perform_agent_actions(World *w, const int *actions)
 {
     int cleaned[CZO_MAX_AGENTS], coll[CZO_MAX_AGENTS], tx[CZO_MAX_AGENTS], ty[CZO_MAX_AGENTS];
     int scheme = w->cfg->action_scheme;
+    /* actions[a] < 0: agent a is despawned -- it is not in the list world_step acts on (cooking_world.py:105-108), but it
+       stays in world.agents (location, orientation; it still blocks interactions aimed at its cell, :116) */
     for (int a = 0; a < w->A; ++a) {
         int act = actions[a];
         if (act >= 1 && act <= 4) {
@@ -503,6 +508,7 @@ static void perform_agent_actions(World *w, const int *actions)
     for (int a = 0; a < w->A; ++a) {
         Agent *ag = &w->ag[a];
         int act = coll[a];
+        if (act < 0) continue;
         if (scheme == 3) {
             int moved = resolve_walking_action(w, ag, act);  /* runs for act == 0 too (re-presses a Switch) */
             if (!moved && act != 0) scheme3_interaction(w, ag, tx[a], ty[a]);

@@ -21,7 +21,13 @@ def recipe_table():
 
 def golden_sets():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(p).startswith("layouts_"))
+                  if not os.path.basename(p).startswith(("layouts_", "spawn_")))
+
+
+def spawn_sets():
+    """Sets captured with agent despawn / respawn on: per-step fixtures (start state, actions with -1 for inactive agents,
+    the world right before the spawn bookkeeping), not one chain -- see tools/gen_golden.py capture_spawn_episode."""
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "spawn_*.npz")))
 
 
 class Episode:
@@ -30,6 +36,8 @@ class Episode:
         self.dims = soa.Dims(*[int(v) for v in g("dims")])
         self.states, self.obs, self.actions = g("states"), g("obs"), g("actions")
         self.rewards, self.terms, self.truncs = g("rewards"), g("terms"), g("truncs")
+        if f"e{i}_pre_states" in z:                      # despawn / respawn sets
+            self.pre_states, self.pre_obs, self.active, self.changed = g("pre_states"), g("pre_obs"), g("active"), g("changed")
         self.statics = meta_ep["statics"]
         self.class_order = meta_ep["class_order"]
         self.seed = meta_ep["seed"]

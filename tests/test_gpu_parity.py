@@ -80,3 +80,43 @@ def test_set_state_observe_roundtrip(name):
         for i, ep in enumerate(eps):
             assert np.array_equal(bits(obs[i]), bits(ep.obs[min(t, len(ep.states) - 1)]))
     h.close()
+
+
+@pytest.mark.parametrize("name", __import__("golden_io").spawn_sets())
+def test_hip_replays_despawn_respawn_steps(name):
+    """Steps captured with agent despawn / respawn on (action -1 = the agent is not in the list world_step acts on):
+    every step on its own, from its captured start state to the world right before the reference's spawn handling."""
+    gs = GoldenSet(name)
+    eps = gs.episodes
+    h, rids, lays = handle_for_set(gs)
+    n, A = len(eps), eps[0].dims.A
+    h.reset(np.arange(n), rids)
+    base = h.get_state()
+    T = max(len(ep.actions) for ep in eps)
+    inactive = 0
+    for t in range(T):
+        recs = base.copy()
+        acts = np.zeros((n, A), dtype=np.int32)
+        for i, ep in enumerate(eps):
+            k = min(t, len(ep.actions) - 1)
+            keep = {w: recs[i, w] for w in (soa.W_LAYOUT, soa.W_EPISODE, soa.W_POOL, soa.W_RECIPES)}
+            recs[i] = ep.states[k]
+            for w, v in keep.items():
+                recs[i, w] = v
+            acts[i] = ep.actions[k]
+        h.set_state(recs)
+        obs, rew, term, trunc = h.step(acts)
+        st = h.get_state()
+        for i, ep in enumerate(eps):
+            if t >= len(ep.actions):
+                continue
+            ctx = f"{name} ep{i} (seed {ep.seed}) step {t} actions {ep.actions[t].tolist()}"
+            if not np.array_equal(strip(st[i]), strip(ep.pre_states[t])):
+                pytest.fail(f"{ctx}: state differs\n-- device\n{soa.describe_record(ep.dims, st[i])}\n-- reference\n"
+                            f"{soa.describe_record(ep.dims, ep.pre_states[t])}")
+            assert np.array_equal(bits(obs[i]), bits(ep.pre_obs[t])), ctx
+            assert np.array_equal(bits(rew[i]), bits(ep.rewards[t])), f"{ctx}: reward {rew[i]} vs {ep.rewards[t]}"
+            assert np.array_equal(term[i], ep.terms[t]) and np.array_equal(trunc[i], ep.truncs[t]), ctx
+            inactive += int((ep.actions[t] < 0).sum())
+    assert inactive > 20
+    h.close()

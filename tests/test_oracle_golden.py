@@ -74,3 +74,35 @@ def test_kat_c3_known_answer():
     assert abs(total - 19.625) < 1e-12
     assert h.hexdigest().startswith("24e17ccb854352dd")
     assert soa.unpack_agent(rec[soa.AGENT_WORD0])[:2] == (2, 1)
+
+
+@pytest.mark.parametrize("name", __import__("golden_io").spawn_sets())
+def test_oracle_replays_despawn_respawn_steps(name):
+    """Agent despawn / respawn (cooking_world.py:267-290) stays host-side bookkeeping; the step path only learns which
+    agents act (action -1 = not in the active list).  Every captured step is replayed on its own: start state (with the
+    previous step's respawn relocation), actions, and the world right before the reference's spawn handling."""
+    gs = GoldenSet(name)
+    n_inactive = n_moved = 0
+    for ei, ep in enumerate(gs.episodes):
+        orc = make_oracle(gs, ep)
+        assert np.array_equal(bits(orc.observe(ep.states[0].copy())), bits(ep.obs[0]))
+        for t in range(len(ep.actions)):
+            rec = ep.states[t].copy()
+            err, obs, rew, term, trunc = orc.step_env(rec, ep.actions[t])
+            ctx = f"{name} ep{ei} (seed {ep.seed}) step {t} actions {ep.actions[t].tolist()}"
+            assert err == 0, ctx
+            assert np.array_equal((ep.actions[t] >= 0).astype(np.uint8), ep.active[t]), ctx
+            if not same_state(ep.dims, rec, ep.pre_states[t]):
+                pytest.fail(f"{ctx}: state differs\n-- oracle\n{soa.describe_record(ep.dims, rec)}\n-- reference\n"
+                            f"{soa.describe_record(ep.dims, ep.pre_states[t])}")
+            assert np.array_equal(bits(obs), bits(ep.pre_obs[t])), ctx
+            assert np.array_equal(bits(rew), bits(ep.rewards[t])), f"{ctx}: reward {rew} vs {ep.rewards[t]}"
+            assert np.array_equal(term, ep.terms[t]) and np.array_equal(trunc, ep.truncs[t]), ctx
+            # what the host-side spawn handling did afterwards: only agent words may differ, and the observation of
+            # the relocated world is the plain encode of that state
+            d = np.flatnonzero(ep.states[t + 1] != ep.pre_states[t])
+            assert all(soa.AGENT_WORD0 <= w < soa.AGENT_WORD0 + ep.dims.A for w in d), ctx
+            n_moved += len(d)
+            assert np.array_equal(bits(orc.observe(ep.states[t + 1].copy())), bits(ep.obs[t + 1])), ctx
+            n_inactive += int((ep.actions[t] < 0).sum())
+    assert n_inactive > 20 and n_moved > 3, (n_inactive, n_moved)      # the sets really exercise both directions

@@ -418,6 +418,92 @@ def capture_episode(cfg, seed, policy_name, max_len=None):
     }
 
 
+def capture_spawn_episode(cfg, seed, policy_name, rates, max_len=None):
+    """One episode with agent despawn/respawn switched on (cooking_world.py:267-290; rates = (despawn, respawn, grace)).
+
+    The build keeps the spawn bookkeeping (two global RNG streams, variable agent sets) on the host and gives the device
+    one extra input: action -1 = "this agent is not in the list world_step acts on".  So the fixture records, per step,
+    the start state (respawn relocations of the previous step applied), the actions with -1 for inactive agents, and the
+    world right BEFORE handle_agent_spawn runs (state + observation of every agent), which is what one device step
+    must reproduce; plus the per-recipe rewards, the done flag and the t >= max_steps flag of the step."""
+    random.seed(seed)
+    np.random.seed(seed)
+    rng = np.random.default_rng(seed + 7919)
+    despawn, respawn, grace = rates
+    env = CookingEnvironment(level=cfg["level"], meta_file=cfg["meta_file"], num_agents=cfg["num_agents"],
+                             max_steps=cfg["max_steps"], recipes=cfg["recipes"],
+                             obs_spaces=["feature_vector"] * cfg["num_agents"],
+                             end_condition_all_dishes=cfg["end_condition_all_dishes"],
+                             action_scheme=cfg["action_scheme"], reward_scheme=cfg.get("reward_scheme"),
+                             agent_respawn_rate=respawn, grace_period=grace, agent_despawn_rate=despawn)
+    env.reset()
+    world = env.world
+    A = cfg["num_agents"]
+    F = env.feature_vector_representation_length
+    D = cfg["max_dyn"]
+    dims = soa.Dims(world.width, world.height, D, A, F)
+    slotmap = SlotMap(world, D)
+    recipe_ids = [RECIPE_NAMES.index(r) for r in cfg["recipes"]]
+    scheme = cfg["action_scheme"]
+    pols = [Bumper(rng, scheme) if (policy_name == "bumper" or (policy_name == "mixed" and i % 2)) else Uniform(rng, scheme)
+            for i in range(A)]
+    snap = {}
+    orig_spawn, orig_rewards = world.handle_agent_spawn, env.compute_rewards
+
+    def spawn_hook():
+        snap["rec"] = world_to_record(env, dims, slotmap, 0, recipe_ids)
+        snap["obs"] = np.stack([env.get_feature_vector(a) for a in env.possible_agents])
+        orig_spawn()
+
+    def rewards_hook(*args, **kw):
+        out = orig_rewards(*args, **kw)
+        snap["dones"], snap["rewards"] = out[0], out[1]
+        return out
+    world.handle_agent_spawn = spawn_hook
+    env.compute_rewards = rewards_hook
+
+    full_obs = lambda: np.stack([env.get_feature_vector(a) for a in env.possible_agents])
+    states = [world_to_record(env, dims, slotmap, 0, recipe_ids)]
+    obs = [full_obs()]
+    active = [list(world.active_agents)]
+    pre_states, pre_obs, actions, rewards, terms, truncs, changed = [], [], [], [], [], [], []
+    limit = max_len or cfg["max_steps"]
+    for step in range(limit):
+        act_now = list(world.active_agents)
+        full = [(pols[i].act(world, i) if act_now[i] else -1) for i in range(A)]
+        try:
+            env.accumulated_step([a for a in full if a >= 0])
+        except IndexError:
+            # reference defect: truncation by max_steps while somebody is despawned sizes active_agents with the CURRENT
+            # agent count (cooking_env.py:337, AECEnv.num_agents) and the scatter loop (:257) runs off its end
+            assert env.t >= cfg["max_steps"] and not all(act_now)
+            break
+        pre = snap["rec"].copy()
+        post = world_to_record(env, dims, slotmap, 0, recipe_ids)
+        pre[soa.W_MARKS] = post[soa.W_MARKS]                  # the graphs are re-evaluated after the world step
+        actions.append(full)
+        pre_states.append(pre)
+        pre_obs.append(snap["obs"])
+        rewards.append([float(snap["rewards"][i]) for i in range(A)])
+        terms.append([bool(snap["dones"][0])] * A)
+        truncs.append([env.t >= cfg["max_steps"]] * A)
+        states.append(post)
+        obs.append(full_obs())
+        active.append(list(world.active_agents))
+        changed.append(list(world.status_changed))
+        if terms[-1][0] or truncs[-1][0]:
+            break
+    return {
+        "dims": np.array(dims.as_tuple(), dtype=np.int32), "states": np.stack(states), "obs": np.stack(obs),
+        "pre_states": np.stack(pre_states), "pre_obs": np.stack(pre_obs),
+        "actions": np.array(actions, dtype=np.int32).reshape(-1, A),
+        "rewards": np.array(rewards, dtype=np.float64).reshape(-1, A),
+        "terms": np.array(terms, dtype=np.uint8).reshape(-1, A), "truncs": np.array(truncs, dtype=np.uint8).reshape(-1, A),
+        "active": np.array(active, dtype=np.uint8).reshape(-1, A), "changed": np.array(changed, dtype=np.uint8).reshape(-1, A),
+        "statics": static_lists(env), "class_order": slotmap.class_order,
+    }
+
+
 def episode_stats(ep):
     """Coverage summary of what an episode reached (for the generator log)."""
     dims = soa.Dims(*[int(v) for v in ep["dims"]])
@@ -447,6 +533,9 @@ def save_set(name, cfg, episodes, out_dir):
     for i, ep in enumerate(episodes):
         for k in ("dims", "states", "obs", "actions", "rewards", "terms", "truncs"):
             arrays[f"e{i}_{k}"] = ep[k]
+        for k in ("pre_states", "pre_obs", "active", "changed"):           # despawn / respawn sets only
+            if k in ep:
+                arrays[f"e{i}_{k}"] = ep[k]
         meta["episodes"].append({"statics": ep["statics"], "class_order": ep["class_order"],
                                  "seed": ep["seed"], "policy": ep["policy"] if isinstance(ep["policy"], str) else "scripted"})
     arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
@@ -583,6 +672,29 @@ def main():
             sets[ename + "_scheme1"] = (lambda n=ename, l=elvl, a=agents, r=recipes: run_set(
                 n + "_scheme1", base_cfg(l, a, r, scheme="scheme1", max_steps=100, meta=metae),
                 [(210, "bumper", 100), (211, "uniform", 100)], args.out))
+    # despawn / respawn (rates > 0): file names start with "spawn_" (the generic chain tests skip them, tests/test_spawn_*.py use them)
+    def spawn_set(name, cfg, plan, rates):
+        eps = []
+        for seed, policy, max_len in plan:
+            ep = capture_spawn_episode(cfg, seed, policy, rates, max_len)
+            ep["seed"], ep["policy"] = seed, policy
+            flips = int(np.abs(np.diff(ep["active"].astype(int), axis=0)).sum())
+            print(f"   {name} seed={seed} policy={policy}: {episode_stats(ep)} activity flips {flips}")
+            eps.append(ep)
+        cfg = dict(cfg, rates=list(rates))
+        return save_set(name, cfg, eps, args.out)
+    sets["spawn_coop_2agents"] = lambda: spawn_set(
+        "spawn_coop_2agents", base_cfg("coop_test", 2, ["TomatoLettuceSalad", "CarrotBanana"], max_steps=150),
+        [(300, "bumper", 150), (301, "uniform", 150), (302, "bumper", 150)], (0.15, 0.3, 2))
+    if os.path.exists(crowd) and os.path.exists(metac):
+        sets["spawn_crowded_4agents"] = lambda: spawn_set(
+            "spawn_crowded_4agents",
+            base_cfg(crowd, 4, ["TomatoSalad", "TomatoLettuceSalad", "no_recipe", "MashedCarrotBanana"], max_steps=160, meta=metac),
+            [(310, "bumper", 160), (311, "uniform", 160), (312, "mixed", 160)], (0.2, 0.25, 1))
+        sets["spawn_crowded_scheme1"] = lambda: spawn_set(
+            "spawn_crowded_scheme1",
+            base_cfg(crowd, 3, ["TomatoSalad", "TomatoLettuceSalad", "MashedCarrotBanana"], scheme="scheme1", max_steps=120, meta=metac),
+            [(320, "bumper", 120), (321, "uniform", 120)], (0.1, 0.2, 3))
     sets["api_traces"] = lambda: api_traces(args.out)
     sets["layouts_ref"] = lambda: layout_draws(args.out)
     sets["aec_traces"] = lambda: aec_traces(args.out)
