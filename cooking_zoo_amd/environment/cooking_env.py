@@ -10,8 +10,11 @@ Same constructor kwargs, method names, dict keys and return shapes as the refere
 
 `env(...)` returns the agent-iterator (AEC) view of the same environment (AECCookingEnvironment below).
 
+Agent despawn / respawn (rates > 0) is supported: the random bookkeeping stays on the host (same global RNG streams as
+the reference), the device step is told who acts.
+
 What is deliberately not offered ("out of scope" / "next"): the "symbolic" and "full" observation modes,
-pygame rendering, agent despawn/respawn rates > 0 and scheme2 (which raises AttributeError in the reference itself).
+pygame rendering and scheme2 (which raises AttributeError in the reference itself).
 For many envs at once use cooking_zoo_amd.vec_env.CookingVecEnv -- this facade is the num_envs = 1 case of it.
 """
 from __future__ import annotations
@@ -69,8 +72,11 @@ class CookingEnvironment:
         if action_scheme == "scheme2":
             raise AttributeError("'CookingWorld' object has no attribute 'perform_agent_action' (scheme2 is unusable in "
                                  "the reference: action_scheme2.py:15)")
-        if agent_respawn_rate or agent_despawn_rate:
-            raise NotImplementedError("agent despawn/respawn (rates > 0) is not part of the accelerated path yet")
+        # agent despawn / respawn (cooking_world.py:267-290): the bookkeeping -- two draws from numpy's global stream per
+        # agent and step, respawn cells from Python's global `random` -- stays on the host, exactly where the reference
+        # does it; the device step only learns which agents act (action -1 = not in the active list)
+        self.agent_respawn_rate, self.agent_despawn_rate, self.grace_period = agent_respawn_rate, agent_despawn_rate, grace_period
+        self._spawning = bool(agent_respawn_rate or agent_despawn_rate)
         self.level, self.meta_file, self.max_steps = level, meta_file, max_steps
         self.action_scheme = action_scheme
         self.action_scheme_class = ACTION_SCHEMES[action_scheme]
@@ -97,6 +103,12 @@ class CookingEnvironment:
                                   device_id=device_id, max_dyn=max(_ll.level_max_dyn(level_object), 1))
         self._level_object, self._meta = level_object, meta
         self._cached_layout = first
+        # parse_agents appends one (x candidates, y candidates) pair per created agent (parsing.py:145)
+        self._spawn_cells = [(spec["X_POSITION"], spec["Y_POSITION"]) for spec in level_object["AGENTS"]
+                             for _ in range(spec["MAX_COUNT"])][:num_agents]
+        self._active = [True] * num_agents
+        self._status_changed = [False] * num_agents
+        self._grace = [grace_period] * num_agents
         self.num_goals = recipe_drawer.NUM_GOALS if recipe_drawer.RECIPE_STORE else recipe_drawer.DEFAULT_NUM_GOALS
         self.recipe_graphs = [self._vec.book[r]() for r in recipes]
         self.loaded_recipes = list(self._vec.book.keys())
@@ -153,6 +165,11 @@ class CookingEnvironment:
             self._vec.set_layouts([self._cached_layout])
         obs = self._vec.reset(layout_ids=[0])
         self._refresh_marks()
+        n = len(self.possible_agents)
+        self._active, self._status_changed = [True] * n, [False] * n            # load_level.py:67-68
+        if options["full_reset"]:
+            self._grace = [self.grace_period] * n                                # a new CookingWorld: parsing.py:142
+        # (a world that is re-used keeps the countdowns of the finished episode: parsing.py appends behind them)
         self.rewards = {a: 0 for a in self.agents}
         self.terminations = {a: False for a in self.agents}
         self.truncations = {a: False for a in self.agents}
@@ -161,36 +178,103 @@ class CookingEnvironment:
         return {a: obs[0, i].copy() for i, a in enumerate(self.agents)}, dict(self.infos)
 
     def step(self, actions):
-        """One accumulated_step (cooking_env.py:243-269) + observe for every agent (cooking_env.py:271-288)."""
+        """One accumulated_step (cooking_env.py:243-269) + observe for every agent (cooking_env.py:271-288).
+        `actions` has one entry per agent in `self.agents` (the active ones)."""
         if self._needs_reset or not self.agents:
             raise RuntimeError("the episode is over (or reset() was never called): call reset() before step()")
-        acts = [int(actions[a]) for a in self.possible_agents]
+        A = len(self.possible_agents)
+        active_start = self._active[:]
+        acts = [int(actions[a]) if active_start[i] else -1 for i, a in enumerate(self.possible_agents)]
         n = self.action_spaces[self.possible_agents[0]].n
-        if any(a < 0 or a >= n for a in acts):
+        if any(active_start[i] and not 0 <= acts[i] < n for i in range(A)):
             raise ValueError(f"actions must be in [0, {n}) for {self.action_scheme}")
         obs, rew, term, trunc = self._vec.step(np.asarray([acts], dtype=np.int32))
         self.t += 1
         self._set_marks(int(self._vec.last_marks()[0]))
-        truncated = bool(trunc[0, 0])
-        if truncated:
+        self._status_changed = [False] * A                                       # cooking_world.py:106
+        if self._spawning and self._handle_agent_spawn():
+            obs = self._vec.observe()                                             # somebody was put on a new cell
+        relevant = [i for i in range(A) if self._active[i] or self._status_changed[i]]   # cooking_world.py:292-293
+        # compute_truncated (cooking_env.py:333-350)
+        out_of_time = bool(trunc[0, 0])
+        if out_of_time:
             self.termination_info = f"Terminating because {self.max_steps} timesteps passed"
+            # (the reference sizes this list with the CURRENT agent count and then indexes past its end when somebody
+            # is despawned at this moment -- IndexError at cooking_env.py:257; the build ends the episode instead)
+            self._active = [False] * A
+            self._status_changed = [i in relevant for i in range(A)]
+        truncated = {i: out_of_time or (self._status_changed[i] and not self._active[i]) for i in relevant}
+        done = bool(term[0, 0])
         info = {"t": self.t, "termination_info": self.termination_info}
         self.rewards, self.terminations, self.truncations, self.infos = {}, {}, {}, {}
         observations = {}
-        for i, a in enumerate(self.possible_agents):
+        for k, i in enumerate(relevant):
+            a = self.possible_agents[i]
             observations[a] = obs[0, i].copy()
-            self.rewards[a] = np.float64(rew[0, i])
-            self.terminations[a] = bool(term[0, i])
-            self.truncations[a] = bool(trunc[0, i])
+            # the reference scatters the per-RECIPE rewards by position in the relevant list (cooking_env.py:255-261):
+            # with everybody present that is the agent's own recipe, otherwise the k-th one
+            self.rewards[a] = np.float64(rew[0, k])
+            self.terminations[a] = done
+            self.truncations[a] = bool(truncated[i])
             self.infos[a] = {"goal_vector": self.goal_vectors[a], **info,
-                             "recipe_done": self.recipe_graphs[i].completed(), "action": acts[i],
-                             "task": self.recipe_names[i]}
-        if truncated or bool(term[0, 0]):
+                             "recipe_done": self.recipe_graphs[i].completed(),
+                             "action": acts[i] if active_start[i] else 0, "task": self.recipe_names[i]}
+        if out_of_time or done:
             # the reference empties the agent list after the final step (truncation: cooking_env.py:336-339,267-268;
             # termination: its wrapper loop cannot make progress, SURVEY A.12(5) -- the build ends the episode cleanly)
             self.agents = []
             self._needs_reset = True
+        else:
+            # whoever was despawned in this step is reported once (truncated) and then leaves the agent list
+            # (cooking_env.py:216-224); whoever was respawned joins it
+            self.agents = [a for i, a in enumerate(self.possible_agents) if self._active[i]]
         return observations, dict(self.rewards), dict(self.terminations), dict(self.truncations), dict(self.infos)
+
+    def _handle_agent_spawn(self):
+        """cooking_world.py:267-290 on the host: same draws from the same global streams as the reference.  Returns
+        True if an agent was moved (the caller re-encodes the observation)."""
+        A = len(self.possible_agents)
+        rec = None
+        moved = False
+        for i in range(A):
+            if self._grace[i] > 0:
+                self._grace[i] -= 1
+                continue
+            if self._active.count(True) > 1 and self._active[i] and np.random.random() < self.agent_despawn_rate:
+                rec = self._vec.get_state()[0] if rec is None else rec
+                if soa.unpack_agent(rec[soa.AGENT_WORD0 + i])[3] >= 0:
+                    continue                                                     # holding something: stays (:280-281)
+                self._active[i] = False
+                self._status_changed[i] = True
+            elif not self._active[i] and np.random.random() < self.agent_respawn_rate:
+                rec = self._vec.get_state()[0] if rec is None else rec
+                self._active[i] = True
+                self._status_changed[i] = True
+                self._grace[i] = self.grace_period
+                x, y = self._generate_location(rec, *self._spawn_cells[i])
+                _, _, o, h = soa.unpack_agent(rec[soa.AGENT_WORD0 + i])
+                rec[soa.AGENT_WORD0 + i] = soa.pack_agent(x, y, o, h)         # location only (cooking_world.py:290)
+                self._vec.set_state(rec[None, :])
+                moved = True
+        return moved
+
+    def _generate_location(self, rec, x_positions, y_positions):
+        """parsing.py:154-167: a Floor cell nobody (active or not) stands on, drawn with `random.sample`."""
+        dims = self._vec.dims
+        cells = soa.record_cells(dims, rec)
+        agents = [soa.unpack_agent(rec[soa.AGENT_WORD0 + a])[:2] for a in range(dims.A)]
+        time_out = 0
+        while True:
+            x = random.sample(x_positions, 1)[0]
+            y = random.sample(y_positions, 1)[0]
+            if x < 0 or y < 0 or x > dims.W or y > dims.H:
+                raise ValueError(f"Position {x} {y} is out of bounds set by the level layout!")
+            on_grid = x < dims.W and y < dims.H
+            if on_grid and (x, y) not in agents and (cells[y * dims.W + x] & soa.CELL_TYPE_MASK) == soa.FLOOR:
+                return int(x), int(y)
+            time_out += 1
+            if time_out > 1000:
+                raise ValueError(f"Can't find valid position in {time_out} steps")
 
     def observe(self, agent):
         return self._vec.observe()[0, self.possible_agents.index(agent)].copy()
@@ -228,6 +312,8 @@ class AECCookingEnvironment:
 
     def __init__(self, *args, **kwargs):
         self._core = CookingEnvironment(*args, **kwargs)
+        if self._core._spawning:
+            raise NotImplementedError("agent despawn / respawn is offered through parallel_env only")
         self.possible_agents = self._core.possible_agents[:]
         self.agents = self.possible_agents[:]
         self.observation_spaces, self.action_spaces = self._core.observation_spaces, self._core.action_spaces

@@ -175,7 +175,8 @@ class CookingVecEnv:
         return obs
 
     def step(self, actions, return_obs=True):
-        """actions int [N, A] -> (obs f64 [N, A, F] | None, rewards f64 [N, A], terminations u8, truncations u8)."""
+        """actions int [N, A] -> (obs f64 [N, A, F] | None, rewards f64 [N, A], terminations u8, truncations u8).
+        An action of -1 means "this agent is despawned": it is left out of the step (cooking_world.py:105-108)."""
         acts = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.num_envs, self.num_agents)
         N, A = self.num_envs, self.num_agents
         obs = np.empty((N, A, self.F), dtype=np.float64) if return_obs else None

@@ -106,6 +106,8 @@ int cz_observe(cz_handle h, int64_t env_begin, int64_t env_count, double *obs);
 /* ---- step ------------------------------------------------------------------------------------------ */
 /* One batched env step = accumulated_step (cooking_env.py:243-269): world_step (cooking_world.py:104-112),
  * compute_rewards (cooking_env.py:290-315), compute_truncated (:333-350), then observe (:271, :352-373).
+ * An action < 0 marks an agent that is not in the list world_step acts on (despawned, cooking_world.py:105-108,267-290):
+ * it does not turn, move, interact or take part in the collision filter, but keeps its cell.
  * Host-pointer form: actions int32 [N][A]; outputs obs float64 [N][A][F] (may be NULL), rewards float64 [N][A],
  * terminations / truncations uint8 [N][A].  Synchronous. */
 int cz_step(cz_handle h, const int32_t *actions, double *obs, double *rewards, uint8_t *terminations,

@@ -29,8 +29,9 @@ def test_parallel_env_matches_reference_trace(case):
     for a, o in case["reset_obs"].items():
         assert obs[a].dtype == np.float64 and np.array_equal(bits(obs[a]), bits(np.array(o)))
     for st in case["steps"]:
-        o, r, te, tr, inf = env.step({f"player_{i}": a for i, a in enumerate(st["actions"])})
-        assert set(o) == set(st["obs"])
+        # (with despawn / respawn rates > 0 the action dict follows env.agents: it was drawn on the fly and recorded)
+        o, r, te, tr, inf = env.step(st.get("action_dict") or {f"player_{i}": a for i, a in enumerate(st["actions"])})
+        assert set(o) == set(st["obs"]) and set(r) == set(st["rewards"]) and set(inf) == set(st["infos"])
         for a in st["obs"]:
             assert np.array_equal(bits(o[a]), bits(np.array(st["obs"][a]))), a
             assert isinstance(r[a], np.float64) and np.array_equal(bits(r[a]), bits(np.array(st["rewards"][a])))
@@ -75,8 +76,9 @@ def test_unsupported_modes_fail_loudly():
         parallel_env(obs_spaces=["symbolic"], action_scheme="scheme3", **kw)
     with pytest.raises(AttributeError):
         parallel_env(action_scheme="scheme2", **kw)
+    from cooking_zoo_amd.environment.cooking_env import env as aec_env
     with pytest.raises(NotImplementedError):
-        parallel_env(action_scheme="scheme3", agent_despawn_rate=0.1, **kw)
+        aec_env(action_scheme="scheme3", agent_despawn_rate=0.1, **kw)      # despawn / respawn: parallel_env only
 
 
 def test_last_marks_matches_state_on_both_host_paths():

@@ -729,12 +729,37 @@ def api_traces(out_dir):
                                                  "recipe_node_reward": 1}),
              actions=[[int(a), int(b)] for a, b in np.random.default_rng(5).integers(0, 8, size=(30, 2))]),
     ]
+    # agent despawn / respawn: the action dict follows env.agents, so it is drawn on the fly (and recorded)
+    crowd = os.path.join(REPO, "cooking_zoo_amd", "utils", "level", "crowded_6x5.json")
+    metac = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", "crowded_6x5.json")
+    cases += [
+        dict(seed=21, kwargs=dict(level="coop_test", meta_file="example", num_agents=2, max_steps=400,
+                                  recipes=["TomatoLettuceSalad", "CarrotBanana"], obs_spaces=["feature_vector", "feature_vector"],
+                                  action_scheme="scheme3", agent_respawn_rate=0.25, grace_period=2, agent_despawn_rate=0.15),
+             actions=None, steps=140, policy_seed=3),
+        dict(seed=22, kwargs=dict(level=crowd, meta_file=metac, num_agents=4, max_steps=400,
+                                  recipes=["TomatoSalad", "TomatoLettuceSalad", "no_recipe", "MashedCarrotBanana"],
+                                  obs_spaces=["feature_vector"] * 4, action_scheme="scheme1",
+                                  agent_respawn_rate=0.2, grace_period=1, agent_despawn_rate=0.2,
+                                  reward_scheme={"recipe_reward": 10, "max_time_penalty": -3, "recipe_penalty": -7,
+                                                 "recipe_node_reward": 1}),
+             actions=None, steps=160, policy_seed=4),
+    ]
     out = []
     for case in cases:
         random.seed(case["seed"])
         np.random.seed(case["seed"])
         env = parallel_env(**case["kwargs"])
         obs, infos = env.reset()
+        if case["actions"] is None:
+            prng = np.random.default_rng(case["policy_seed"])
+            n_act = int(env.action_space("player_0").n)
+            case = dict(case, actions=[None] * case["steps"])
+        kw = dict(case["kwargs"])
+        for key in ("level", "meta_file"):                    # build-shipped files are referred to by stem
+            if os.path.isabs(kw[key]):
+                kw[key] = os.path.splitext(os.path.basename(kw[key]))[0]
+        case = dict(case, kwargs=kw)
         rec = {"seed": case["seed"], "kwargs": case["kwargs"], "possible_agents": list(env.possible_agents),
                "reset_obs": {k: v.tolist() for k, v in obs.items()}, "reset_infos": {k: dict(v) for k, v in infos.items()},
                "obs_shape": list(env.observation_space("player_0").shape), "n_actions": int(env.action_space("player_0").n),
@@ -742,10 +767,13 @@ def api_traces(out_dir):
         for acts in case["actions"]:
             if not env.agents:
                 break
-            ad = {f"player_{i}": a for i, a in enumerate(acts)}
+            if acts is None:
+                ad = {a: int(prng.integers(n_act)) for a in env.agents}
+            else:
+                ad = {f"player_{i}": a for i, a in enumerate(acts)}
             o, r, te, tr, inf = env.step(ad)
             rec["steps"].append({
-                "actions": acts, "obs": {k: v.tolist() for k, v in o.items()},
+                "actions": acts, "action_dict": ad, "obs": {k: v.tolist() for k, v in o.items()},
                 "rewards": {k: float(v) for k, v in r.items()}, "terminations": {k: bool(v) for k, v in te.items()},
                 "truncations": {k: bool(v) for k, v in tr.items()},
                 "infos": {k: {kk: (vv.tolist() if hasattr(vv, "tolist") else vv) for kk, vv in v.items()} for k, v in inf.items()},
