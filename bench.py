@@ -176,6 +176,14 @@ def main():
     else:
         total_env_steps = local_env_steps
 
+    # the floor of a launch that has to emit this much output: same grid shape, nothing but the stores
+    out_only_us = None
+    if not args.no_obs:
+        us = C.c_float()
+        out_bytes = N * 2 * env.F * 8
+        if L.cz_probe_output_only(h, d_obs.ptr, out_bytes, 500, C.byref(us)) == 0:
+            out_only_us = float(us.value)
+
     # dominant-kernel duration: HIP events bracket the timed region on the kernels' own stream; the K launches run
     # back to back (rocprofv3 --kernel-trace shows no gaps, profiles/), so duration = event time / K
     kernel_us = ev_ms.value * 1e3 / K
@@ -261,7 +269,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(f"k_step_{N}"),
                          "kernel": "cz::k_step<1,1,2,3,false> (one wavefront per env, 8 envs per workgroup)", "kernel_us": kernel_us, "alg_bytes_per_env_step": b_alg,
-                         "units_per_launch": N},
+                         "units_per_launch": N,
+                         # measured on this box, same run: a kernel of the same grid shape that ONLY writes the observation
+                         # bytes (write-through 16-byte stores); write-only traffic does not reach the 8 TB/s read+write peak
+                         "output_only_launch_us": out_only_us,
+                         "frac_of_output_only_launch": (out_only_us / kernel_us) if out_only_us else None},
             "achieved_hbm_gbs_end_to_end": b_alg * value / 1e9 / world,
         }
         if fused is not None:

@@ -62,6 +62,16 @@ __global__ void k_stats_clear(uint32_t *su, double *sf, const uint32_t *__restri
 }
 
 // cz_reset on envs whose episode is still running: their steps stay counted as env-steps
+// measurement aid (cz_probe_output_only): a grid of the step kernel's shape that does nothing but write `bytes` with the
+// same write-through 16-byte stores the observation encode uses -- the floor of any launch that has to emit that much
+__global__ __launch_bounds__(64 * ENVS_PER_WG) void k_probe_fill(void *dst, uint32_t bytes) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)bytes, 0x00020000);
+    const uint32_t stride = gridDim.x * blockDim.x * 16u;
+    for (uint32_t off = (blockIdx.x * blockDim.x + threadIdx.x) * 16u; off + 16u <= bytes; off += stride)
+        __builtin_amdgcn_raw_buffer_store_b128(u4{0, 0, 0, 0}, rs, off, 0, 16);
+}
+
 __global__ void k_count_aborted(uint32_t *su, const uint32_t *__restrict__ state, int RW, long long env_begin, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -548,6 +558,24 @@ extern "C" int cz_last_marks(cz_handle h, uint32_t *out) {
     if (!out) return fail(h, "cz_last_marks: null buffer");
     if (h->last_marks.size() != (size_t)h->P.N) return fail(h, "cz_last_marks: no cz_step has run on this handle yet");
     memcpy(out, h->last_marks.data(), (size_t)h->P.N * 4);
+    return 0;
+}
+
+// Measurement aid for bench.py: `reps` back-to-back launches of a kernel with the step kernel's grid shape that only
+// writes `bytes` (<= 2 GiB) to d_dst; returns the average launch duration.  d_dst is overwritten with zeros.
+extern "C" int cz_probe_output_only(cz_handle h, void *d_dst, size_t bytes, int32_t reps, float *us_per_launch) {
+    if (ready(h)) return 1;
+    if (!d_dst || !us_per_launch || reps < 1 || bytes < 16 || bytes > ((size_t)1 << 31)) return fail(h, "cz_probe_output_only: bad arguments");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const dim3 grid((unsigned)((h->P.N + ENVS_PER_WG - 1) / ENVS_PER_WG)), block(64 * ENVS_PER_WG);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_probe_fill, grid, block, 0, h->stream, d_dst, (uint32_t)bytes);
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_probe_fill, grid, block, 0, h->stream, d_dst, (uint32_t)bytes);
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *us_per_launch = ms * 1e3f / (float)reps;
     return 0;
 }
 

@@ -149,6 +149,10 @@ int cz_timer_stop(cz_handle h, float *elapsed_ms);         /* record + synchroni
 /* brackets every kernel launch of the step path with HIP events and accumulates device time */
 int cz_kernel_time_reset(cz_handle h, int32_t enable);
 int cz_kernel_time_read(cz_handle h, double *total_ms, int64_t *launches);
+/* measurement aid: average duration of `reps` back-to-back launches of a kernel of the step kernel's grid shape that does
+ * nothing but write `bytes` (<= 2 GiB) to d_dst with the encode's 16-byte write-through stores -- the floor of a launch
+ * that has to emit that much output (bench.py reports it next to the roofline).  d_dst is overwritten. */
+int cz_probe_output_only(cz_handle h, void *d_dst, size_t bytes, int32_t reps, float *us_per_launch);
 
 /* ---- statistics + multi-GPU ------------------------------------------------------------------------- */
 int cz_get_stats(cz_handle h, cz_stats *out);              /* device reduction over this handle's envs */
