@@ -173,10 +173,20 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, "cz_create: device_id %d out of range", cfg->device_id);
     cz_handle h = new cz_handle_s();
     h->cfg = *cfg;
-    HIPCHK(nullptr, hipSetDevice(cfg->device_id));
-    HIPCHK(nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(nullptr, hipEventCreate(&h->ev0));
-    HIPCHK(nullptr, hipEventCreate(&h->ev1));
+    // from here on a failure must release what was already created
+#define CREATE_CHK(call)                                                                          \
+    do {                                                                                          \
+        hipError_t _e = (call);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            fail(nullptr, "cz_create: %s failed: %s", #call, hipGetErrorString(_e));             \
+            cz_destroy(h);                                                                        \
+            return 1;                                                                             \
+        }                                                                                         \
+    } while (0)
+    CREATE_CHK(hipSetDevice(cfg->device_id));
+    CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_CHK(hipEventCreate(&h->ev0));
+    CREATE_CHK(hipEventCreate(&h->ev1));
     Params &P = h->P;
     memset(&P, 0, sizeof P);
     P.N = cfg->num_envs; P.A = cfg->num_agents; P.W = cfg->width; P.H = cfg->height; P.D = cfg->max_dyn; P.F = cfg->feat_len;
@@ -203,14 +213,14 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
         P.reward_idle = x;
     }
     const size_t N = (size_t)P.N;
-    HIPCHK(nullptr, hipMalloc(&h->d_state, N * P.RW * 4));
-    HIPCHK(nullptr, hipMemsetAsync(h->d_state, 0, N * P.RW * 4, h->stream));
-    HIPCHK(nullptr, hipMalloc(&h->d_stat_u, N * SU_WORDS * 4));
-    HIPCHK(nullptr, hipMalloc(&h->d_stat_f, N * SF_WORDS * 8));
-    HIPCHK(nullptr, hipMemsetAsync(h->d_stat_u, 0, N * SU_WORDS * 4, h->stream));
-    HIPCHK(nullptr, hipMemsetAsync(h->d_stat_f, 0, N * SF_WORDS * 8, h->stream));
-    HIPCHK(nullptr, hipMalloc(&h->d_stats_out, sizeof(cz_stats)));
-    HIPCHK(nullptr, hipStreamSynchronize(h->stream));
+    CREATE_CHK(hipMalloc(&h->d_state, N * P.RW * 4));
+    CREATE_CHK(hipMemsetAsync(h->d_state, 0, N * P.RW * 4, h->stream));
+    CREATE_CHK(hipMalloc(&h->d_stat_u, N * SU_WORDS * 4));
+    CREATE_CHK(hipMalloc(&h->d_stat_f, N * SF_WORDS * 8));
+    CREATE_CHK(hipMemsetAsync(h->d_stat_u, 0, N * SU_WORDS * 4, h->stream));
+    CREATE_CHK(hipMemsetAsync(h->d_stat_f, 0, N * SF_WORDS * 8, h->stream));
+    CREATE_CHK(hipMalloc(&h->d_stats_out, sizeof(cz_stats)));
+    CREATE_CHK(hipStreamSynchronize(h->stream));
     P.state = h->d_state; P.stat_u = h->d_stat_u; P.stat_f = h->d_stat_f;
     {   // observation quotients: (x - ax) / W and (y - ay) / H for every possible difference, computed here with the same
         // IEEE-754 double division Python's int / int true division performs (cooking_env.py:364-368)
@@ -219,13 +229,18 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
         for (int i = 0; i < 2 * P.W - 1; ++i) lut[i] = (double)(i - (P.W - 1)) / (double)P.W;
         for (int i = 0; i < 2 * P.H - 1; ++i) lut[LUT_Y0 + i] = (double)(i - (P.H - 1)) / (double)P.H;
         lut[LUT_ZERO] = 0.0; lut[LUT_ONE] = 1.0;
-        HIPCHK(nullptr, hipMalloc(&h->d_lut, sizeof lut));
-        HIPCHK(nullptr, hipMemcpy(h->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+        CREATE_CHK(hipMalloc(&h->d_lut, sizeof lut));
+        CREATE_CHK(hipMemcpy(h->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
         P.lut = h->d_lut;
         P.inv_w = (65536u + (uint32_t)P.W - 1u) / (uint32_t)P.W;
         for (uint32_t c = 0; c < 1024; ++c)
-            if (((c * P.inv_w) >> 16) != c / (uint32_t)P.W) return fail(nullptr, "cz_create: internal: inexact cell division for W=%d", P.W);
+            if (((c * P.inv_w) >> 16) != c / (uint32_t)P.W) {
+                fail(nullptr, "cz_create: internal: inexact cell division for W=%d", P.W);
+                cz_destroy(h);
+                return 1;
+            }
     }
+#undef CREATE_CHK
     *out = h;
     return 0;
 }
@@ -239,6 +254,7 @@ extern "C" int cz_destroy(cz_handle h) {
         destroy_t f = (destroy_t)dlsym(h->rccl, "ncclCommDestroy");
         if (f) f(h->comm);
     }
+    if (h->rccl) (void)dlclose(h->rccl);
     void *ptrs[] = {h->d_lut, h->d_state, h->d_lay_init, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out,
                     h->d_actions, h->d_obs, h->d_rew, h->d_term, h->d_trunc, h->d_gather, h->d_marks};
     for (void *p : ptrs)
@@ -357,6 +373,18 @@ static int check_range(cz_handle h, int64_t b, int64_t c) {
 
 extern "C" int cz_set_state(cz_handle h, int64_t b, int64_t c, const uint32_t *records) {
     if (check_range(h, b, c)) return 1;
+    if (c == 0) return 0;
+    if (!records) return fail(h, "cz_set_state: null buffer");
+    // the words the kernels use as table indices must be in range (everything else lives in registers / LDS)
+    for (int64_t i = 0; i < c; ++i) {
+        const uint32_t *r = records + (size_t)i * h->P.RW;
+        if (h->n_layouts > 0 && r[W_LAYOUT] >= (uint32_t)h->n_layouts) return fail(h, "cz_set_state: record %lld: layout id %u out of range", (long long)i, r[W_LAYOUT]);
+        for (int k = 0; k < h->P.R; ++k)
+            if (h->n_recipes > 0 && ((r[W_RECIPES] >> (8 * k)) & 0xFFu) >= (uint32_t)h->n_recipes)
+                return fail(h, "cz_set_state: record %lld: recipe id %u out of range", (long long)i, (r[W_RECIPES] >> (8 * k)) & 0xFFu);
+        const uint32_t base = r[W_POOL] & 0xFFFFu, count = r[W_POOL] >> 16;
+        if (count && h->n_layouts > 0 && (int)(base + count) > h->n_layouts) return fail(h, "cz_set_state: record %lld: layout pool slice out of range", (long long)i);
+    }
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipMemcpyAsync(h->d_state + (size_t)b * h->P.RW, records, (size_t)c * h->P.RW * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -365,11 +393,21 @@ extern "C" int cz_set_state(cz_handle h, int64_t b, int64_t c, const uint32_t *r
 
 extern "C" int cz_get_state(cz_handle h, int64_t b, int64_t c, uint32_t *records) {
     if (check_range(h, b, c)) return 1;
+    if (c == 0) return 0;
+    if (!records) return fail(h, "cz_get_state: null buffer");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipMemcpyAsync(records, h->d_state + (size_t)b * h->P.RW, (size_t)c * h->P.RW * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
+
+// device scratch of one call: released on every return path
+struct Scratch {
+    void *p = nullptr;
+    ~Scratch() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
 
 static int ready(cz_handle h) {
     if (!h) return fail(nullptr, "null handle");
@@ -416,25 +454,23 @@ extern "C" int cz_reset(cz_handle h, int64_t b, int64_t c, const int32_t *layout
             pools[(size_t)i] = pool_words[i];
         }
     }
-    int32_t *d_lay = nullptr;
-    uint32_t *d_rec = nullptr, *d_pool = nullptr;
-    double *d_obs = nullptr;
-    HIPCHK(h, hipMalloc(&d_lay, (size_t)c * 4));
-    HIPCHK(h, hipMalloc(&d_rec, (size_t)c * 4));
-    HIPCHK(h, hipMalloc(&d_pool, (size_t)c * 4));
-    HIPCHK(h, hipMemcpyAsync(d_lay, layout_ids, (size_t)c * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(d_rec, recipe_ids, (size_t)c * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(d_pool, pools.data(), (size_t)c * 4, hipMemcpyHostToDevice, h->stream));
+    Scratch s_lay, s_rec, s_pool, s_obs;
+    HIPCHK(h, s_lay.alloc((size_t)c * 4));
+    HIPCHK(h, s_rec.alloc((size_t)c * 4));
+    HIPCHK(h, s_pool.alloc((size_t)c * 4));
+    HIPCHK(h, hipMemcpyAsync(s_lay.p, layout_ids, (size_t)c * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(s_rec.p, recipe_ids, (size_t)c * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(s_pool.p, pools.data(), (size_t)c * 4, hipMemcpyHostToDevice, h->stream));
     size_t ob = (size_t)c * h->P.A * h->P.F * 8;
-    if (obs) HIPCHK(h, hipMalloc(&d_obs, ob));
+    if (obs) HIPCHK(h, s_obs.alloc(ob));
     Params P = h->P;
     hipLaunchKernelGGL(k_count_aborted, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, h->stream, h->d_stat_u, h->d_state, h->P.RW,
                        (long long)b, (int)c);
-    HIPCHK(h, h->kl.reset(P, h->stream, b, (int)c, d_lay, d_rec, d_pool, d_obs));
-    if (obs) HIPCHK(h, hipMemcpyAsync(obs, d_obs, ob, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    (void)hipFree(d_lay); (void)hipFree(d_rec); (void)hipFree(d_pool);
-    if (d_obs) (void)hipFree(d_obs);
+    hipError_t rc = h->kl.reset(P, h->stream, b, (int)c, s_lay.as<int32_t>(), s_rec.as<uint32_t>(), s_pool.as<uint32_t>(), s_obs.as<double>());
+    if (rc == hipSuccess && obs) rc = hipMemcpyAsync(obs, s_obs.p, ob, hipMemcpyDeviceToHost, h->stream);
+    const hipError_t rs = hipStreamSynchronize(h->stream);            // the scratch must outlive the kernel in any case
+    HIPCHK(h, rc);
+    HIPCHK(h, rs);
     return 0;
 }
 
@@ -444,14 +480,15 @@ extern "C" int cz_observe(cz_handle h, int64_t b, int64_t c, double *obs) {
     if (c == 0) return 0;
     if (!obs) return fail(h, "cz_observe: null buffer");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    double *d_obs = nullptr;
+    Scratch s_obs;
     size_t ob = (size_t)c * h->P.A * h->P.F * 8;
-    HIPCHK(h, hipMalloc(&d_obs, ob));
+    HIPCHK(h, s_obs.alloc(ob));
     Params P = h->P;
-    HIPCHK(h, h->kl.observe(P, h->stream, b, (int)c, d_obs));
-    HIPCHK(h, hipMemcpyAsync(obs, d_obs, ob, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    (void)hipFree(d_obs);
+    hipError_t rc = h->kl.observe(P, h->stream, b, (int)c, s_obs.as<double>());
+    if (rc == hipSuccess) rc = hipMemcpyAsync(obs, s_obs.p, ob, hipMemcpyDeviceToHost, h->stream);
+    const hipError_t rs = hipStreamSynchronize(h->stream);
+    HIPCHK(h, rc);
+    HIPCHK(h, rs);
     return 0;
 }
 

@@ -60,6 +60,18 @@ def test_bad_descriptor_and_ids_are_rejected():
     env._upload_layouts()
     with pytest.raises(_native.NativeError, match="layout id"):
         env.reset(layout_ids=[0, 1, 2, 0])
+    # records handed to cz_set_state may not point the kernels outside their tables
+    from cooking_zoo_amd import soa
+    env.reset()
+    good = env.get_state()
+    for word, value, what in ((soa.W_LAYOUT, 7, "layout id"), (soa.W_RECIPES, 0x0000FE00, "recipe id"),
+                              (soa.W_POOL, (3 << 16) | 1, "layout pool")):
+        bad = good.copy()
+        bad[2, word] = value
+        with pytest.raises(_native.NativeError, match=what):
+            env.set_state(bad)
+    env.set_state(good)
+    assert np.array_equal(env.get_state(), good)
     with pytest.raises(Exception):
         CookingVecEnv(4, "coop_test", "example", 2, 10, ["TomatoLettuceSalad"], action_scheme="scheme3")   # one recipe per agent
     with pytest.raises(ValueError, match="scheme2"):
