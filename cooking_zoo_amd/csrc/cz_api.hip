@@ -254,7 +254,6 @@ extern "C" int cz_destroy(cz_handle h) {
         destroy_t f = (destroy_t)dlsym(h->rccl, "ncclCommDestroy");
         if (f) f(h->comm);
     }
-    if (h->rccl) (void)dlclose(h->rccl);
     void *ptrs[] = {h->d_lut, h->d_state, h->d_lay_init, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out,
                     h->d_actions, h->d_obs, h->d_rew, h->d_term, h->d_trunc, h->d_gather, h->d_marks};
     for (void *p : ptrs)
@@ -559,8 +558,10 @@ extern "C" int cz_step(cz_handle h, const int32_t *actions, double *obs, double 
         memcpy(h->h_stage + o_act, actions, NA * 4);
         h->marks_out_next = (uint32_t *)(h->d_stage + o_marks);
         if (cz_step_device(h, (const int32_t *)(h->d_stage + o_act), obs ? (double *)(h->d_stage + o_obs) : nullptr,
-                           (double *)(h->d_stage + o_rew), (uint8_t *)(h->d_stage + o_term), (uint8_t *)(h->d_stage + o_trunc)))
+                           (double *)(h->d_stage + o_rew), (uint8_t *)(h->d_stage + o_term), (uint8_t *)(h->d_stage + o_trunc))) {
+            h->marks_out_next = nullptr;
             return 1;
+        }
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (obs) memcpy(obs, h->h_stage + o_obs, ob);
         memcpy(rewards, h->h_stage + o_rew, NA * 8);
@@ -579,8 +580,11 @@ extern "C" int cz_step(cz_handle h, const int32_t *actions, double *obs, double 
     if (obs && !h->d_obs) HIPCHK(h, hipMalloc(&h->d_obs, ob));
     HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, NA * 4, hipMemcpyHostToDevice, h->stream));
     h->marks_out_next = h->d_marks;
+    if (cz_step_device(h, h->d_actions, obs ? h->d_obs : nullptr, h->d_rew, h->d_term, h->d_trunc)) {
+        h->marks_out_next = nullptr;
+        return 1;
+    }
     h->last_marks.resize((size_t)h->P.N);
-    if (cz_step_device(h, h->d_actions, obs ? h->d_obs : nullptr, h->d_rew, h->d_term, h->d_trunc)) return 1;
     HIPCHK(h, hipMemcpyAsync(h->last_marks.data(), h->d_marks, (size_t)h->P.N * 4, hipMemcpyDeviceToHost, h->stream));
     if (obs) HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, ob, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(rewards, h->d_rew, NA * 8, hipMemcpyDeviceToHost, h->stream));
@@ -723,7 +727,9 @@ extern "C" int cz_comm_unique_id(uint8_t id[128]) {
 }
 extern "C" int cz_comm_init(cz_handle h, int32_t n_ranks, int32_t rank, const uint8_t id[128]) {
     if (!h) return fail(nullptr, "null handle");
-    h->rccl = rccl_lib(h);
+    if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(h, "cz_comm_init: bad arguments");
+    if (h->comm) return fail(h, "cz_comm_init: this handle already has a communicator");
+    h->rccl = rccl_lib(h);                       // (process-wide handle, never unloaded)
     if (!h->rccl) return 1;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     typedef int (*fn_t)(void **, int, cz_nccl_id, int);
