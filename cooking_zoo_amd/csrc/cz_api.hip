@@ -86,7 +86,8 @@ __global__ void k_count_aborted(uint32_t *su, const uint32_t *__restrict__ state
 struct cz_handle_s {
     cz_config cfg;
     Params P;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every call of this handle is ordered on
+    hipStream_t own_stream = nullptr;  // the one cz_create made (cz_set_stream may point `stream` at a caller's)
     Launchers kl;
     int n_layouts = 0, n_recipes = 0;
     uint32_t *d_state = nullptr, *d_lay_init = nullptr, *d_lay_desc = nullptr, *d_recipes = nullptr;
@@ -184,7 +185,8 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
         }                                                                                         \
     } while (0)
     CREATE_CHK(hipSetDevice(cfg->device_id));
-    CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_CHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
     CREATE_CHK(hipEventCreate(&h->ev0));
     CREATE_CHK(hipEventCreate(&h->ev1));
     Params &P = h->P;
@@ -262,11 +264,21 @@ extern "C" int cz_destroy(cz_handle h) {
     for (hipEvent_t e : h->kev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return 0;
 }
 
+// Order this handle's work on a stream of the caller (e.g. the current stream of the framework that produces the
+// actions and consumes the observations), so that no host synchronisation is needed in between.  NULL = back to the
+// handle's own stream.  Work already queued on the previous stream is waited for first.
+extern "C" int cz_set_stream(cz_handle h, void *hip_stream) {
+    if (!h) return fail(nullptr, "null handle");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return 0;
+}
 extern "C" int32_t cz_record_words(cz_handle h) { return h ? h->P.RW : 0; }
 extern "C" int cz_sync(cz_handle h) {
     if (!h) return fail(nullptr, "null handle");

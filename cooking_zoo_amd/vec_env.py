@@ -51,6 +51,19 @@ class DeviceBuffer:
             self.ptr = None
 
 
+def _dev_ptr(b):
+    """device address of a DeviceBuffer / raw int / object with data_ptr() (e.g. a torch tensor); None stays None"""
+    if b is None:
+        return None
+    if hasattr(b, "ptr"):
+        return b.ptr
+    if hasattr(b, "data_ptr"):
+        if hasattr(b, "is_contiguous") and not b.is_contiguous():
+            raise ValueError("device buffers must be contiguous")
+        return C.c_void_p(b.data_ptr())
+    return C.c_void_p(int(b))
+
+
 def resolve_recipe_tables(recipes):
     """-> (registry dict, names list).  Same rule as cooking_env.py:100-105: a non-empty user
     RECIPE_STORE replaces the default book."""
@@ -204,13 +217,22 @@ class CookingVecEnv:
         self._buffers.append(b)
         return b
 
+    def set_stream(self, stream=None):
+        """Order this env's device work on the caller's HIP stream: an int / ctypes pointer, or an object with a
+        `cuda_stream` attribute such as torch.cuda.current_stream().  None = the env's own stream."""
+        raw = getattr(stream, "cuda_stream", stream)
+        _native.check(self._h, _native.lib().cz_set_stream(self._h, C.c_void_p(int(raw)) if raw else None))
+
     def step_device(self, d_actions, d_obs, d_rewards, d_term, d_trunc):
-        p = lambda b: b.ptr if b is not None else None
+        """Device-resident step.  Buffers: DeviceBuffer, a raw device address (int), or anything with `data_ptr()`
+        (a torch tensor on this GPU: int32 [N, A] actions, float64 [N, A, F] observations, float64 [N, A] rewards,
+        uint8 [N, A] flags, all contiguous)."""
+        p = _dev_ptr
         _native.check(self._h, _native.lib().cz_step_device(self._h, p(d_actions), p(d_obs), p(d_rewards), p(d_term),
                                                             p(d_trunc)))
 
     def rollout(self, T, seed, step0=0, d_obs=None, d_rewards=None, d_term=None, d_trunc=None):
-        p = lambda b: b.ptr if b is not None else None
+        p = _dev_ptr
         _native.check(self._h, _native.lib().cz_rollout(self._h, int(T), int(seed), int(step0), p(d_obs), p(d_rewards),
                                                         p(d_term), p(d_trunc)))
 

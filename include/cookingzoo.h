@@ -9,7 +9,7 @@
  *
  * Conventions: every function returns 0 on success, non-zero on failure with a message available from
  * cz_last_error(handle) (or cz_last_error(NULL) for creation failures).  One host thread per handle;
- * one HIP stream per handle; the caller owns every buffer it passes; the library owns device state
+ * one HIP stream per handle (its own, or the caller's after cz_set_stream); the caller owns every buffer it passes; the library owns device state
  * until cz_destroy.  "d_" parameters are device pointers (from cz_dev_alloc or any HIP allocation).
  *
  * Per-env state travels as a flat "record" of cz_record_words() little-endian uint32 words:
@@ -73,6 +73,10 @@ int32_t cz_sizeof_config(void);                           /* sizeof(cz_config), 
 int32_t cz_sizeof_stats(void);
 int cz_debug_set_stamps(cz_handle h, void *d_buf);       /* diagnostic builds only (make prof): s_memtime stamp buffer */
 int cz_sync(cz_handle h);                                  /* wait for the handle's stream */
+/* Order all further work of this handle on a HIP stream of the caller (hipStream_t; e.g. the stream a framework runs its
+ * policy on: device-pointer steps then need no host synchronisation on either side).  NULL restores the handle's own
+ * stream.  The stream must belong to the handle's device and outlive its use here. */
+int cz_set_stream(cz_handle h, void *hip_stream);
 
 /* ---- tables ---------------------------------------------------------------------------------------- */
 /* Recipe graphs: replaces RECIPES[name]() / Recipe.node_list (recipe_drawer.py:109-118, recipe.py:29-34).

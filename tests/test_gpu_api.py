@@ -150,3 +150,4 @@ def test_aec_env_matches_reference_trace(case):
             dead.step(0)
         dead.step(0)                                  # truncated: only None is valid now
     e.close()
+

@@ -1,0 +1,62 @@
+"""GPU + PyTorch in one process: device-pointer steps on torch tensors, ordered on torch's stream.
+
+PyTorch's ROCm wheels bundle their own libamdhip64.so.7; the step library links the system one under the same SONAME.
+Whichever is loaded first serves both, and only the order "torch first" is supported by torch -- so this file must be
+the first thing in its process that touches the GPU (inside a full `pytest tests -m gpu` run it skips itself)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_torch_tensors_on_the_callers_stream():
+    """Device-pointer steps driven from PyTorch: tensors as buffers, the env ordered on torch's current stream
+    (cz_set_stream), no host synchronisation between the producer of the actions, the step and the consumer."""
+    from cooking_zoo_amd import _native
+    if _native._lib is not None:
+        pytest.skip("the HIP library is already loaded in this process: run this file on its own "
+                    "(python -m pytest tests/test_gpu_zz_torch_interop.py -m gpu), torch must start the HIP runtime")
+    torch = pytest.importorskip("torch")
+    torch.cuda.init()                    # torch first: the library then binds to the same HIP runtime (same SONAME)
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    n, A, T = 512, 2, 40
+    kw = dict(action_scheme="scheme3", num_layouts=8, auto_reset=True)
+    env = CookingVecEnv(n, "coop_test", "example", A, 25, ["TomatoLettuceSalad", "CarrotBanana"], **kw)
+    ref = CookingVecEnv(n, "coop_test", "example", A, 25, ["TomatoLettuceSalad", "CarrotBanana"], **kw)
+    env.reset(return_obs=False)
+    ref.reset(return_obs=False)
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    obs = torch.empty((n, A, env.F), dtype=torch.float64, device=dev)
+    rew = torch.empty((n, A), dtype=torch.float64, device=dev)
+    term = torch.empty((n, A), dtype=torch.uint8, device=dev)
+    trunc = torch.empty((n, A), dtype=torch.uint8, device=dev)
+    ret = torch.zeros((n, A), dtype=torch.float64, device=dev)
+    acts_log, obs_sum = [], []
+    with torch.cuda.stream(side):
+        env.set_stream(torch.cuda.current_stream())
+        for t in range(T):
+            acts = torch.randint(0, 5, (n, A), dtype=torch.int32, device=dev, generator=gen)      # "policy" on the GPU
+            env.step_device(acts, obs, rew, term, trunc)
+            ret += rew                                                                           # consumer on the GPU
+            obs_sum.append(obs.sum())
+            acts_log.append(acts)
+        side.synchronize()
+    env.set_stream(None)
+    want_ret = np.zeros((n, A))
+    for t in range(T):
+        o, r, te, tr = ref.step(acts_log[t].cpu().numpy())
+        want_ret += r
+        assert float(obs_sum[t].cpu()) == float(torch.from_numpy(o).sum()) or np.isclose(float(obs_sum[t].cpu()), o.sum(), rtol=1e-12)
+    assert np.array_equal(bits(obs.cpu().numpy()), bits(o)) and np.array_equal(term.cpu().numpy(), te)
+    assert np.array_equal(bits(ret.cpu().numpy()), bits(want_ret))
+    assert np.array_equal(env.get_state(), ref.get_state())
+    with pytest.raises(ValueError):
+        env.step_device(acts_log[0].t(), obs, rew, term, trunc)                                  # not contiguous
+    env.close()
+    ref.close()
