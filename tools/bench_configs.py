@@ -60,12 +60,17 @@ def measure(name, env, steps=300, warm=30, fused_T=32):
 
 
 def main():
-    which = sys.argv[1:] or ["cfg2", "cfg2_16k", "cfg2_64k", "cfg3", "cfg5"]
+    which = sys.argv[1:] or ["cfg2", "cfg2_16k", "cfg4_shard", "cfg2_64k", "cfg3", "cfg5"]
     L = os.path.join(REPO, "cooking_zoo_amd", "utils", "level")
     if "cfg2" in which:
         measure("cfg2: 4096 envs coop_test 2 agents", CookingVecEnv(4096, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3", num_layouts=256))
     if "cfg2_16k" in which:
         measure("cfg2 workload at 16384 envs", CookingVecEnv(16384, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3", num_layouts=256), steps=200)
+    if "cfg4_shard" in which:
+        # config 4 = 262 144 envs over 8 GPUs: what ONE of its ranks runs (global env ids 98 304..131 071 = rank 3)
+        measure("cfg4: one rank's shard of 262144 envs over 8 GPUs (32768 envs, env_id_base 98304)",
+                CookingVecEnv(32768, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3",
+                              num_layouts=256, env_id_base=98304), steps=150, fused_T=16)
     if "cfg2_64k" in which:
         measure("cfg2 workload at 65536 envs", CookingVecEnv(65536, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3", num_layouts=256), steps=100, fused_T=16)
     if "cfg3" in which:
