@@ -133,20 +133,17 @@ def main():
     d_rew = env.alloc((N, 2), np.float64)
     d_term = env.alloc((N, 2), np.uint8)
     d_trunc = env.alloc((N, 2), np.uint8)
-    step_bytes = N * 2 * 4
     obs_ptr = None if args.no_obs else d_obs.ptr
 
     def run_steps(k, first):
-        # k launches of the step kernel, one per env step (cz_step_device issued k times from C)
-        assert first % chunk == 0 or True
-        done = 0
-        while done < k:
-            off = (first + done) % chunk
-            n = min(k - done, chunk - off)
-            rc = L.cz_step_device_many(h, n, d_actions.ptr + off * step_bytes, N * 2, chunk, obs_ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr)
-            if rc:
-                _native.check(h, rc)
-            done += n
+        # k launches of the step kernel, one per env step, issued from C; step j reads slot (first + j) % chunk of the
+        # action ring (aligned runs of 32 launches are replayed from HIP graphs: cz_step_device_ring)
+        rc = L.cz_step_device_ring(h, k, d_actions.ptr, N * 2, chunk, first % chunk, obs_ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr)
+        if rc:
+            _native.check(h, rc)
+
+    # one-off graph capture outside the measurement (it steps nothing)
+    _native.check(h, L.cz_ring_prepare(h, d_actions.ptr, N * 2, chunk, obs_ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr))
 
     def barrier():
         env.sync()
@@ -265,7 +262,7 @@ def main():
                                    f"256-layout pool, on-device auto-reset, feature_vector obs F={env.F} f64, "
                                    f"uniform random actions",
                        "envs_per_gpu": N, "parallelism": f"env-sharded x{world}, one wavefront per env",
-                       "api": "cz_step_device_many: one kernel launch per env step, actions/obs/rewards/flags resident in HBM"},
+                       "api": "cz_step_device_ring: one kernel launch per env step (runs of 32 launches replayed from HIP graphs), actions/obs/rewards/flags resident in HBM"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(f"k_step_{N}"),
                          "kernel": "cz::k_step<1,1,2,3,false> (one wavefront per env, 8 envs per workgroup)", "kernel_us": kernel_us, "alg_bytes_per_env_step": b_alg,

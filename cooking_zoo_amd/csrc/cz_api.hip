@@ -102,6 +102,17 @@ struct cz_handle_s {
     uint32_t *d_marks = nullptr, *marks_out_next = nullptr;   // (cz_step hands the kernel a marks buffer for one launch)
     std::vector<uint32_t> last_marks;          // recipe marks after the most recent cz_step (cz_last_marks)
     char *h_stage = nullptr, *d_stage = nullptr;   // small batches: pinned, device-mapped staging block of cz_step
+    // cz_step_device_ring: replayable graphs of RING_SEG consecutive launches each (one per aligned segment of the ring)
+    struct RingKey {
+        const int32_t *ring = nullptr; int64_t stride = 0; int32_t period = 0;
+        double *obs = nullptr, *rew = nullptr; uint8_t *term = nullptr, *trunc = nullptr; hipStream_t stream = nullptr; uint64_t version = 0;
+        bool operator==(const RingKey &o) const {
+            return ring == o.ring && stride == o.stride && period == o.period && obs == o.obs && rew == o.rew && term == o.term &&
+                   trunc == o.trunc && stream == o.stream && version == o.version;
+        }
+    } ring_key;
+    std::vector<hipGraphExec_t> ring_graphs;
+    uint64_t tables_version = 0;                   // bumped whenever something the launches capture by value changes
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // kernel timing
     bool ktime = false;
@@ -114,6 +125,7 @@ struct cz_handle_s {
     void *comm = nullptr;
     int n_ranks = 1, rank = 0;
     int wt_override = -1;          // CZ_WT experiment switch, read once
+    bool graphs_enabled = true;    // CZ_GRAPHS=0: cz_step_device_ring launches everything directly
     size_t zero_copy_bytes = (size_t)256 << 10;   // cz_step: batches whose buffers fit use the pinned device-mapped block (CZ_ZERO_COPY_BYTES)
     cz_stats *d_gather = nullptr;
     std::string err;
@@ -203,6 +215,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     P.T = 1;
     P.stop = -1;
     if (const char *s = getenv("CZ_WT")) h->wt_override = atoi(s);
+    if (const char *s = getenv("CZ_GRAPHS")) h->graphs_enabled = atoi(s) != 0;
     if (const char *s = getenv("CZ_ZERO_COPY_BYTES")) h->zero_copy_bytes = (size_t)atoll(s);
     if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // honoured by the diagnostic build only
     h->kl = (P.D <= 64 && C <= 64) ? launchers_small() : launchers_large();
@@ -260,6 +273,8 @@ extern "C" int cz_destroy(cz_handle h) {
                     h->d_actions, h->d_obs, h->d_rew, h->d_term, h->d_trunc, h->d_gather, h->d_marks};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (hipGraphExec_t g : h->ring_graphs)
+        if (g) (void)hipGraphExecDestroy(g);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     for (hipEvent_t e : h->kev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -277,6 +292,7 @@ extern "C" int cz_set_stream(cz_handle h, void *hip_stream) {
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->tables_version++;
     return 0;
 }
 extern "C" int32_t cz_record_words(cz_handle h) { return h ? h->P.RW : 0; }
@@ -326,6 +342,7 @@ extern "C" int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->n_recipes = n;
     h->P.recipes = h->d_recipes;
+    h->tables_version++;
     // Carrying an object from cell to cell changes no co-location (hence no recipe mark) when at most two agents
     // exist (they can never share a cell, cooking_world.py:206-221) and no recipe relates a dynamic-class node to a
     // node of a walkable static class (Floor, Switch, Block) -- the only statics a carried object can be "at".
@@ -372,6 +389,7 @@ extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const 
     HIPCHK(h, hipMemcpyAsync(h->d_lay_desc, obs_desc, b1, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->n_layouts = n;
+    h->tables_version++;
     h->P.lay_init = h->d_lay_init; h->P.lay_desc = h->d_lay_desc; h->P.L = n;
     return 0;
 }
@@ -536,6 +554,84 @@ extern "C" int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_acti
     for (int32_t k = 0; k < K; ++k) {
         P.actions = d_actions + (int64_t)(k % action_period) * action_stride;
         if (launch_step(h, P)) return 1;
+    }
+    return 0;
+}
+
+// The same K launches for callers that keep their actions in a ring of `period` slots (slot s at d_ring + s * stride):
+// step k reads slot (first_slot + k) % period.  Aligned runs of RING_SEG slots are captured once into a graph and
+// replayed afterwards, which takes the host out of the loop (0.02 us instead of ~2.5 us of CPU per launch) and lets the
+// kernels read their arguments from memory that is not rewritten before every launch.  Everything else is launched
+// directly; results are identical to cz_step_device_many.
+constexpr int RING_SEG = 32;
+// captures the launches of slots [slot, slot + RING_SEG) (nothing executes) and instantiates them
+static int ring_capture(cz_handle h, Params &P, const int32_t *d_ring, int64_t stride, int32_t slot, hipGraphExec_t &ge) {
+    hipGraph_t g = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int bad = 0;
+    for (int s = 0; s < RING_SEG && !bad; ++s) {
+        P.actions = d_ring + (int64_t)(slot + s) * stride;
+        bad = launch_step(h, P);
+    }
+    const hipError_t ec = hipStreamEndCapture(h->stream, &g);
+    if (bad) { if (g) (void)hipGraphDestroy(g); return 1; }
+    HIPCHK(h, ec);
+    const hipError_t ei = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ei != hipSuccess) { ge = nullptr; HIPCHK(h, ei); }
+    return 0;
+}
+static bool ring_select(cz_handle h, const int32_t *d_ring, int64_t stride, int32_t period, double *d_obs, double *d_rewards,
+                        uint8_t *d_term, uint8_t *d_trunc) {
+    if (h->ktime || !h->graphs_enabled || period % RING_SEG != 0) return false;
+    cz_handle_s::RingKey key;
+    key.ring = d_ring; key.stride = stride; key.period = period; key.obs = d_obs; key.rew = d_rewards; key.term = d_term;
+    key.trunc = d_trunc; key.stream = h->stream; key.version = h->tables_version;
+    if (!(key == h->ring_key)) {
+        for (hipGraphExec_t g : h->ring_graphs)
+            if (g) (void)hipGraphExecDestroy(g);
+        h->ring_graphs.assign((size_t)(period / RING_SEG), nullptr);
+        h->ring_key = key;
+    }
+    return true;
+}
+// Builds every graph cz_step_device_ring would build lazily for this ring and these output buffers, without stepping
+// anything (so that a measurement does not pay the one-off capture inside its timed region).
+extern "C" int cz_ring_prepare(cz_handle h, const int32_t *d_ring, int64_t stride, int32_t period, double *d_obs, double *d_rewards,
+                               uint8_t *d_term, uint8_t *d_trunc) {
+    if (ready(h)) return 1;
+    if (!d_ring || period < 1) return fail(h, "cz_ring_prepare: bad arguments");
+    if (set_device(h)) return 1;
+    if (!ring_select(h, d_ring, stride, period, d_obs, d_rewards, d_term, d_trunc)) return 0;
+    Params P = h->P;
+    P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
+    for (int32_t slot = 0; slot < period; slot += RING_SEG) {
+        hipGraphExec_t &ge = h->ring_graphs[(size_t)(slot / RING_SEG)];
+        if (!ge && ring_capture(h, P, d_ring, stride, slot, ge)) return 1;
+    }
+    return 0;
+}
+extern "C" int cz_step_device_ring(cz_handle h, int32_t K, const int32_t *d_ring, int64_t stride, int32_t period, int32_t first_slot,
+                                   double *d_obs, double *d_rewards, uint8_t *d_term, uint8_t *d_trunc) {
+    if (ready(h)) return 1;
+    if (!d_ring || K < 1 || period < 1 || first_slot < 0 || first_slot >= period) return fail(h, "cz_step_device_ring: bad arguments");
+    if (set_device(h)) return 1;
+    Params P = h->P;
+    P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
+    const bool graphs = ring_select(h, d_ring, stride, period, d_obs, d_rewards, d_term, d_trunc);
+    int32_t k = 0;
+    while (k < K) {
+        const int32_t slot = (int32_t)(((int64_t)first_slot + k) % period);
+        if (graphs && slot % RING_SEG == 0 && K - k >= RING_SEG) {
+            hipGraphExec_t &ge = h->ring_graphs[(size_t)(slot / RING_SEG)];
+            if (!ge && ring_capture(h, P, d_ring, stride, slot, ge)) return 1;
+            HIPCHK(h, hipGraphLaunch(ge, h->stream));
+            k += RING_SEG;
+        } else {
+            P.actions = d_ring + (int64_t)slot * stride;
+            if (launch_step(h, P)) return 1;
+            k += 1;
+        }
     }
     return 0;
 }

@@ -131,6 +131,16 @@ int cz_step_device(cz_handle h, const int32_t *d_actions, double *d_obs, double 
 int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_actions, int64_t action_stride, int32_t action_period,
                         double *d_obs, double *d_rewards, uint8_t *d_terminations, uint8_t *d_truncations);
 
+/* The same for actions kept in a ring of `action_period` slots (slot s at d_ring + s * action_stride): step k reads slot
+ * (first_slot + k) % action_period.  Aligned runs of 32 slots are captured into HIP graphs on first use and replayed
+ * afterwards (no host work per launch, stable kernel-argument memory); identical results. */
+int cz_step_device_ring(cz_handle h, int32_t K, const int32_t *d_ring, int64_t action_stride, int32_t action_period,
+                        int32_t first_slot, double *d_obs, double *d_rewards, uint8_t *d_terminations, uint8_t *d_truncations);
+
+/* Optional: build all graphs of a ring up front (nothing is stepped), e.g. before a timed region. */
+int cz_ring_prepare(cz_handle h, const int32_t *d_ring, int64_t action_stride, int32_t action_period, double *d_obs,
+                    double *d_rewards, uint8_t *d_terminations, uint8_t *d_truncations);
+
 /* T fused steps in one launch with on-device uniform random actions (counter-based stream keyed by
  * (seed, global env id, agent, step0 + t)); state stays in registers between steps.  d_obs, if not NULL,
  * is a trajectory buffer [T][N][A][F]; d_rewards [T][N][A]; d_term/d_trunc [T][N][A] (each may be NULL

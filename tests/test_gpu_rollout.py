@@ -275,3 +275,47 @@ def test_fused_trajectory_with_many_descriptor_chunks():
         oo, _, _, _ = orc.step(acts)
         assert np.array_equal(bits(obs[t]), bits(oo)), f"obs @ fused step {t}"
     env.close()
+
+
+def test_ring_api_with_graph_replay_matches_direct_launches():
+    """cz_step_device_ring (aligned runs of 32 launches captured into HIP graphs, replayed on later calls) against
+    cz_step_device_many on a twin env: odd start slots, wrap-around, K below / across / far above the segment size."""
+    import ctypes as C
+    from cooking_zoo_amd import _native
+    n, A, period = 256, 2, 64
+    kw = dict(max_steps=37, num_layouts=8)
+    env, ref = make(n, **kw), make(n, **kw)
+    L = _native.lib()
+    rng = np.random.default_rng(3)
+    ring = rng.integers(0, 5, size=(period, n, A), dtype=np.int32)
+    bufs = []
+    for e in (env, ref):
+        e.reset(return_obs=False)
+        d_ring = e.alloc((period, n, A), np.int32)
+        d_ring.from_host(ring)
+        bufs.append((d_ring, e.alloc((n, A, e.F), np.float64), e.alloc((n, A), np.float64), e.alloc((n, A), np.uint8),
+                     e.alloc((n, A), np.uint8)))
+    slot = 0
+    for K in (5, 40, 1, 70, 200, 33, 64, 31):
+        (r, o, w, t, u), (r2, o2, w2, t2, u2) = bufs
+        _native.check(env._h, L.cz_step_device_ring(env._h, K, r.ptr, n * A, period, slot, o.ptr, w.ptr, t.ptr, u.ptr))
+        done = 0
+        while done < K:                                              # the same steps, launched one by one
+            s = (slot + done) % period
+            k = min(K - done, period - s)
+            _native.check(ref._h, L.cz_step_device_many(ref._h, k, r2.ptr + s * n * A * 4, n * A, period, o2.ptr, w2.ptr, t2.ptr, u2.ptr))
+            done += k
+        slot = (slot + K) % period
+        env.sync(); ref.sync()
+        assert np.array_equal(env.get_state(), ref.get_state()), K
+        assert np.array_equal(bits(o.to_host()), bits(o2.to_host())) and np.array_equal(bits(w.to_host()), bits(w2.to_host())), K
+        assert np.array_equal(t.to_host(), t2.to_host()) and np.array_equal(u.to_host(), u2.to_host()), K
+    assert env.stats() == ref.stats()
+    # new tables invalidate the captured launches
+    env.set_layouts(env.layouts)
+    ref.set_layouts(ref.layouts)
+    _native.check(env._h, L.cz_step_device_ring(env._h, 64, bufs[0][0].ptr, n * A, period, 0, *[b.ptr for b in bufs[0][1:]]))
+    _native.check(ref._h, L.cz_step_device_many(ref._h, 64, bufs[1][0].ptr, n * A, period, *[b.ptr for b in bufs[1][1:]]))
+    env.sync(); ref.sync()
+    assert np.array_equal(env.get_state(), ref.get_state())
+    env.close(); ref.close()
