@@ -106,6 +106,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = torch = None
     if world > 1 or os.environ.get("CZ_BENCH_FORCE_DIST"):      # (the variable exercises the multi-rank code path on one GPU)
+        # torch first, and torch owns the GPU runtime of this process: its wheel bundles libamdhip64.so.7 / librccl.so.1
+        # under the system libraries' SONAMEs, whichever copy is loaded first serves everybody, and only this order is
+        # clean (library first: RCCL bring-up fails on the mixed stack and the process aborts in a destructor at exit;
+        # measured).  Cost: 1-4 % per step against the system runtime of the single-GPU run.
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
