@@ -174,8 +174,10 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     if (cfg->num_agents < 1 || cfg->num_agents > MAX_AGENTS) return fail(nullptr, "cz_create: num_agents must be 1..4");
     if (cfg->num_recipes < cfg->num_agents || cfg->num_recipes > MAX_AGENTS)
         return fail(nullptr, "cz_create: need num_agents <= num_recipes <= 4 (one recipe per agent, cooking_env.py:329)");
-    if (cfg->width < 1 || cfg->height < 1 || cfg->width > 32 || cfg->height > 32 || C > 256)
-        return fail(nullptr, "cz_create: grid %dx%d unsupported (W,H <= 32 and W*H <= 256)", cfg->width, cfg->height);
+    // (the quotient table holds 2W-1 x-entries from index 0 and 2H-1 y-entries from index 64, below the constants at 126/127)
+    if (cfg->width < 1 || cfg->height < 1 || cfg->width > 32 || cfg->height > 31 || C > 256)
+        return fail(nullptr, "cz_create: grid %dx%d unsupported (W <= 32, H <= 31 and W*H <= 256)", cfg->width, cfg->height);
+    static_assert(2 * 32 - 1 <= LUT_Y0 && LUT_Y0 + 2 * 31 - 1 <= LUT_ZERO, "quotient table layout");
     if (cfg->max_dyn < 1 || cfg->max_dyn > 128) return fail(nullptr, "cz_create: max_dyn must be 1..128");
     if (cfg->action_scheme != 1 && cfg->action_scheme != 3)
         return fail(nullptr, "cz_create: action_scheme must be 1 or 3 (scheme2 is unusable in the reference)");

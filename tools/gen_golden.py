@@ -695,6 +695,16 @@ def main():
             "spawn_crowded_scheme1",
             base_cfg(crowd, 3, ["TomatoSalad", "TomatoLettuceSalad", "MashedCarrotBanana"], scheme="scheme1", max_steps=120, meta=metac),
             [(320, "bumper", 120), (321, "uniform", 120)], (0.1, 0.2, 3))
+    metal = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", "limits.json")
+    for lname in ("limit_32x8", "limit_8x31"):
+        llvl = os.path.join(REPO, "cooking_zoo_amd", "utils", "level", lname + ".json")
+        if os.path.exists(llvl) and os.path.exists(metal):
+            sets[lname] = (lambda n=lname, l=llvl: run_set(
+                n, base_cfg(l, 3, ["TomatoSalad", "MashedCarrotBanana", "TomatoLettuceSalad"], max_steps=150, meta=metal),
+                [(400, "bumper", 150), (401, "uniform", 150), (402, "mixed", 150)], args.out))
+            sets[lname + "_scheme1"] = (lambda n=lname, l=llvl: run_set(
+                n + "_scheme1", base_cfg(l, 2, ["TomatoSalad", "CarrotBanana"], scheme="scheme1", max_steps=100, meta=metal),
+                [(410, "bumper", 100), (411, "uniform", 100)], args.out))
     sets["api_traces"] = lambda: api_traces(args.out)
     sets["layouts_ref"] = lambda: layout_draws(args.out)
     sets["aec_traces"] = lambda: aec_traces(args.out)

@@ -107,6 +107,31 @@ def edge_levels():
     return out, meta
 
 
+def limit_levels():
+    """the largest grids the kernels take: 32 columns (W <= 32) and 31 rows (H <= 31), both close to the 256-cell cap;
+    they exercise the ends of the observation quotient table ((x - ax) / W for |x - ax| up to 31, (y - ay) / H up to 30)"""
+    out = {}
+    one = lambda name, x, y: {name: {"COUNT": 1, "X_POSITION": [x], "Y_POSITION": [y]}}
+    for name, W, H in (("limit_32x8", 32, 8), ("limit_8x31", 8, 31)):
+        rows = ["-" * W] + ["-" + " " * (W - 2) + "-" for _ in range(H - 2)] + ["-" * W]
+        statics = [one("Cutboard", 0, 2), one("Cutboard", W - 1, H - 3), one("Blender", 3, H - 1), one("Deliversquare", 4, 0),
+                   one("Switch", 2, 3), one("Block", W - 3, H - 4)]
+        dyn = [{"Plate": {"COUNT": 2, "X_POSITION": [0, W - 1], "Y_POSITION": list(range(1, H - 1))}},
+               {"Tomato": {"COUNT": 2, "X_POSITION": list(range(1, W - 1)), "Y_POSITION": [0, H - 1]}},
+               {"Carrot": {"COUNT": 1, "X_POSITION": list(range(1, W - 1)), "Y_POSITION": [0, H - 1]}},
+               {"Banana": {"COUNT": 1, "X_POSITION": [0, W - 1], "Y_POSITION": list(range(1, H - 1))}},
+               {"Bread": {"COUNT": 2, "X_POSITION": list(range(1, W - 1)), "Y_POSITION": [0, H - 1], "OPTIONAL": 0.8}},
+               {"Lettuce": {"COUNT": 1, "X_POSITION": [0, W - 1], "Y_POSITION": list(range(1, H - 1))}}]
+        # agents start in opposite corners so that the extreme coordinate differences occur from the first step on
+        agents = [dict(MAX_COUNT=1, X_POSITION=[1], Y_POSITION=[1]), dict(MAX_COUNT=1, X_POSITION=[W - 2], Y_POSITION=[H - 2]),
+                  dict(MAX_COUNT=1, X_POSITION=list(range(1, W - 1)), Y_POSITION=list(range(1, H - 1)))]
+        out[name] = {"LEVEL_LAYOUT": "\n".join(rows), "STATIC_OBJECTS": statics, "DYNAMIC_OBJECTS": dyn, "AGENTS": agents,
+                     "DYNAMIC_EXCLUDED_POSITIONS": [[0, 0], [W - 1, 0], [0, H - 1], [W - 1, H - 1]]}
+    meta = [{"Switch": 1}, {"Block": 1}, {"Agent": 3}, {"Cutboard": 2}, {"Counter": 80}, {"Blender": 1}, {"Deliversquare": 1},
+            {"Plate": 2}, {"Tomato": 2}, {"Carrot": 1}, {"Banana": 1}, {"Bread": 4}, {"Lettuce": 1}]
+    return out, meta
+
+
 def main():
     os.makedirs(LEVEL_DIR, exist_ok=True)
     os.makedirs(META_DIR, exist_ok=True)
@@ -120,6 +145,10 @@ def main():
     for name, lv in levels.items():
         dump_level(os.path.join(LEVEL_DIR, name + ".json"), lv)
     dump_meta(os.path.join(META_DIR, "edge.json"), meta)
+    levels, meta = limit_levels()
+    for name, lv in levels.items():
+        dump_level(os.path.join(LEVEL_DIR, name + ".json"), lv)
+    dump_meta(os.path.join(META_DIR, "limits.json"), meta)
     if os.path.isdir(REF):
         for name in ("coop_test", "coexistence_test", "switch_test"):
             with open(os.path.join(REF, "level", name + ".json")) as f:
