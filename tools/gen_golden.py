@@ -695,6 +695,17 @@ def main():
             "spawn_crowded_scheme1",
             base_cfg(crowd, 3, ["TomatoSalad", "TomatoLettuceSalad", "MashedCarrotBanana"], scheme="scheme1", max_steps=120, meta=metac),
             [(320, "bumper", 120), (321, "uniform", 120)], (0.1, 0.2, 3))
+    dense = os.path.join(REPO, "cooking_zoo_amd", "utils", "level", "dense_16x16.json")
+    metad = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", "dense_16x16.json")
+    if os.path.exists(dense) and os.path.exists(metad):
+        sets["dense16_4agents"] = lambda: run_set(
+            "dense16_4agents",
+            base_cfg(dense, 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"], max_steps=120, meta=metad),
+            [(500, "bumper", 120), (501, "uniform", 120), (502, "mixed", 120)], args.out)
+        sets["dense16_scheme1"] = lambda: run_set(
+            "dense16_scheme1",
+            base_cfg(dense, 2, ["TomatoLettuceOnionSalad", "MashedCarrotBanana"], scheme="scheme1", max_steps=80, meta=metad),
+            [(510, "bumper", 80), (511, "uniform", 80)], args.out)
     metal = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", "limits.json")
     for lname in ("limit_32x8", "limit_8x31"):
         llvl = os.path.join(REPO, "cooking_zoo_amd", "utils", "level", lname + ".json")

@@ -107,6 +107,36 @@ def edge_levels():
     return out, meta
 
 
+def dense_16x16():
+    """every dynamic-object slot in use: 122 objects + 3 Bread originals with 3 clone slots = 128 = the kernels' cap"""
+    W = H = 16
+    rows = []
+    for y in range(H):
+        row = ""
+        for x in range(W):
+            border = x in (0, W - 1) or y in (0, H - 1)
+            block = 2 <= x <= 13 and y in (2, 3, 5, 6, 8, 9, 11, 12)
+            row += "-" if (border or block) else " "
+        rows.append(row)
+    n_counters = sum(r.count("-") for r in rows)
+    one = lambda name, x, y: {name: {"COUNT": 1, "X_POSITION": [x], "Y_POSITION": [y]}}
+    statics = [one("Cutboard", x, y) for x, y in [(2, 3), (13, 3), (2, 12), (13, 12)]]
+    statics += [one("Blender", 0, 7), one("Blender", 15, 7), one("Deliversquare", 7, 0), one("Deliversquare", 8, 15)]
+    allx, ally = list(range(W)), list(range(H))
+    counts = [("Plate", 10)] + [(n, 14) for n in ["Tomato", "Onion", "Lettuce", "Carrot", "Banana", "Apple", "Watermelon", "Cucumber"]] + [("Bread", 3)]
+    dyn = [{name: {"COUNT": c, "X_POSITION": allx, "Y_POSITION": ally}} for name, c in counts]
+    agents = [{"MAX_COUNT": 1, "X_POSITION": [1], "Y_POSITION": list(range(1, 15))},
+              {"MAX_COUNT": 1, "X_POSITION": [14], "Y_POSITION": list(range(1, 15))},
+              {"MAX_COUNT": 1, "X_POSITION": list(range(2, 14)), "Y_POSITION": [4, 7]},
+              {"MAX_COUNT": 1, "X_POSITION": list(range(2, 14)), "Y_POSITION": [10, 13]}]
+    lv = {"LEVEL_LAYOUT": "\n".join(rows), "STATIC_OBJECTS": statics, "DYNAMIC_OBJECTS": dyn, "AGENTS": agents,
+          "DYNAMIC_EXCLUDED_POSITIONS": [[0, 0], [15, 0], [0, 15], [15, 15]]}
+    meta = [{"Cutboard": 4}, {"Counter": n_counters}, {"Blender": 2}, {"Deliversquare": 2}] + \
+           [{n: c} for n, c in counts[:-1]] + [{"Bread": 6}, {"Agent": 4}]
+    assert sum(c for _, c in counts) + 3 == 128
+    return lv, meta
+
+
 def limit_levels():
     """the largest grids the kernels take: 32 columns (W <= 32) and 31 rows (H <= 31), both close to the 256-cell cap;
     they exercise the ends of the observation quotient table ((x - ax) / W for |x - ax| up to 31, (y - ay) / H up to 30)"""
@@ -145,6 +175,9 @@ def main():
     for name, lv in levels.items():
         dump_level(os.path.join(LEVEL_DIR, name + ".json"), lv)
     dump_meta(os.path.join(META_DIR, "edge.json"), meta)
+    lv, meta = dense_16x16()
+    dump_level(os.path.join(LEVEL_DIR, "dense_16x16.json"), lv)
+    dump_meta(os.path.join(META_DIR, "dense_16x16.json"), meta)
     levels, meta = limit_levels()
     for name, lv in levels.items():
         dump_level(os.path.join(LEVEL_DIR, name + ".json"), lv)
