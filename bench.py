@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the CookingZoo step() hot path on MI355X (BASELINE.json metric).
 
-A "step" is one batched env step (one `cz_step_device` launch) over every env of the rank: world dynamics, recipe
+A "step" is one batched env step (one launch of the step kernel) over every env of the rank: world dynamics, recipe
 checks, rewards and the float64 feature-vector encode of all agents, with actions and outputs resident in HBM.
 Workload at N GPUs = BASELINE config 2 per GPU (weak scaling): 4096 envs, level coop_test, 2 agents, recipes
 [TomatoLettuceSalad, CarrotBanana], scheme3, max_steps 400, a pool of 256 layouts, next-step auto-reset, uniform
 random actions.  Prints ONE JSON line on rank 0.
 
-    python bench.py --gpus 1 --steps 2000 --warmup 200
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W       # N > 1: starts N fresh processes itself (one per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W          # or under any launcher that sets RANK/LOCAL_RANK/WORLD_SIZE
+
+No torch anywhere: every rank runs on the system ROCm runtime; the ranks of the node meet through a tmpfs directory
+(cooking_zoo_amd.distributed.FileRendezvous) and, for the barrier of the timed region and the episode-statistics
+all-gather, through the C-ABI's own RCCL communicator (cz_comm_init / cz_comm_barrier / cz_stats_allgather).
+
+Timing: W warmup steps, then the K-step region is timed `--repeats` times; every region is bracketed by a stream
+synchronisation + barrier over all ranks on both sides, its time is the MAX over ranks, and `value` / `ms_per_step` are
+the MEDIAN over the regions (min and max are reported next to it).
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -25,19 +34,35 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+COMM_DEADLINE_S = 120.0
+EXIT_COMM_FAILED = 3
 
 
 def algorithmic_bytes_per_env_step(env):
     """SURVEY.md 8(d):  A(8F + 8 + 1 + 1) written + 4A actions read + 2*S_dyn + W*H static cells read,
     S_dyn = 4A + 4D + action objects + linked + 4 (t) + ceil(nodes/8).  4655 B for config 2 (D = 12: 10 objects + 2
     Bread clones, 4 action objects: 3 Cutboards + 1 Blender, 8 recipe nodes)."""
-    A, F, C = env.num_agents, env.F, env.dims.C
+    A, F, C_ = env.num_agents, env.F, env.dims.C
     D = max(l.slots_used for l in env.layouts)
     n_action = max(len(l.static_lists.get("Cutboard", [])) + len(l.static_lists.get("Blender", [])) for l in env.layouts)
     n_linked = max(len(l.static_lists.get("Switch", [])) + len(l.static_lists.get("Block", [])) for l in env.layouts)
     nodes = sum(int(env.recipe_table[r][0]) for r in env.recipe_ids[0][:env.num_recipes])
     s_dyn = 4 * A + 4 * D + n_action + n_linked + 4 + (nodes + 7) // 8
-    return A * (8 * F + 10) + 4 * A + 2 * s_dyn + C
+    return A * (8 * F + 10) + 4 * A + 2 * s_dyn + C_
+
+
+def reference_python_timing():
+    """The unmodified reference timed in the build container (tools/time_reference.py; the reference cannot travel to the
+    GPU box), committed as data under profiles/."""
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*", "reference_python_timing.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        d["source"] = os.path.relpath(files[-1], REPO) + " (tools/time_reference.py, build container)"
+        return d
+    except Exception:
+        return None
 
 
 def cpu_baseline(env, seconds_target=15.0):
@@ -71,9 +96,13 @@ def cpu_baseline(env, seconds_target=15.0):
     reps = int(min(max(seconds_target / max(dt1, 1e-3), 1), 2000))
     dt = run_all(reps, 2)
     total = cores * envs_per_thread * T * reps
-    return {"value": total / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/cz_oracle.c, {cores} threads x {envs_per_thread} envs x {T * reps} steps of the bench "
-                      f"workload incl. obs encode ({total} env-steps in {dt:.1f} s); one thread alone: {single:.0f} env-steps/s"}
+    out = {"value": total / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": f"oracle/cz_oracle.c, {cores} threads x {envs_per_thread} envs x {T * reps} steps of the bench "
+                     f"workload incl. obs encode ({total} env-steps in {dt:.1f} s); one thread alone: {single:.0f} env-steps/s"}
+    ref = reference_python_timing()
+    if ref is not None:
+        out["reference_python"] = ref
+    return out
 
 
 def pmc_traffic(kernel_key):
@@ -91,205 +120,263 @@ def pmc_traffic(kernel_key):
     return best
 
 
-def main():
+def with_deadline(fn, seconds):
+    """fn() on a helper thread; -> (finished, result or exception)."""
+    box = {}
+
+    def run():
+        try:
+            box["r"] = fn()
+        except Exception as exc:                     # noqa: BLE001
+            box["r"] = exc
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(timeout=seconds)
+    return (not th.is_alive()), box.get("r")
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=30, help="how many times the K-step region is timed (median reported)")
     ap.add_argument("--envs", type=int, default=4096, help="env instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="ablation only: skip the observation encode (INVALID as a result)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work at all: every rank reports made-up timings so that the launcher / rendezvous / "
+                         "aggregation path can be exercised on a machine without GPUs (the line is marked INVALID)")
+    return ap.parse_args(argv)
 
+
+def aggregate(per_rank, K):
+    """per_rank: one dict per rank with lists `elapsed_s`, `env_steps`, `kernel_us` (one entry per timed region).
+    -> per-region whole-job throughput: sum of the ranks' env-steps / the slowest rank's time."""
+    R = len(per_rank[0]["elapsed_s"])
+    elapsed = [max(p["elapsed_s"][r] for p in per_rank) for r in range(R)]
+    steps = [sum(p["env_steps"][r] for p in per_rank) for r in range(R)]
+    rate = [s / e for s, e in zip(steps, elapsed)]
+    order = sorted(range(R), key=lambda r: rate[r])
+    med = order[R // 2] if R % 2 else None
+    value = rate[med] if med is not None else 0.5 * (rate[order[R // 2 - 1]] + rate[order[R // 2]])
+    ms = sorted(e * 1e3 / K for e in elapsed)
+    ms_med = ms[R // 2] if R % 2 else 0.5 * (ms[R // 2 - 1] + ms[R // 2])
+    return {"value": value, "value_min": min(rate), "value_max": max(rate), "ms_per_step": ms_med, "ms_per_step_min": ms[0],
+            "ms_per_step_max": ms[-1], "env_steps_per_region": steps[order[R // 2]], "repeats": R}
+
+
+def worker(args):
+    from cooking_zoo_amd import distributed as czd
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = torch = None
-    if world > 1 or os.environ.get("CZ_BENCH_FORCE_DIST"):      # (the variable exercises the multi-rank code path on one GPU)
-        # torch first, and torch owns the GPU runtime of this process: its wheel bundles libamdhip64.so.7 / librccl.so.1
-        # under the system libraries' SONAMEs, whichever copy is loaded first serves everybody, and only this order is
-        # clean (library first: RCCL bring-up fails on the mixed stack and the process aborts in a destructor at exit;
-        # measured).  Cost: 1-4 % per step against the system runtime of the single-GPU run.
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    from cooking_zoo_amd import _native, distributed as czd
-    from cooking_zoo_amd.vec_env import CookingVecEnv
-
-    N = args.envs
-    K, Wm = args.steps, args.warmup
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used", file=sys.stderr)
+    rdzv = czd.FileRendezvous.from_env(timeout=600.0)
+    N, K, Wm, R = args.envs, args.steps, args.warmup, max(1, args.repeats)
     begin, count = czd.shard_range(N * world, world, rank)
+
+    if args.dry_run:
+        mine = {"elapsed_s": [1e-3 * (rank + 1 + 0.01 * r) for r in range(R)], "env_steps": [K * count] * R,
+                "kernel_us": [1.0] * R, "stats": {"env_steps": K * count * R}}
+        every = [json.loads(b) for b in rdzv.all_gather(json.dumps(mine).encode())]
+        if rank == 0:
+            line = {"metric": "env-steps/sec at N parallel envs (1/2/4/8 GPU) + achieved HBM GB/s", "unit": "env-steps/s",
+                    "n_gpus": world, "steps": K, "warmup": Wm, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "u8/u32 state, f64 obs+reward", "data": "DRY RUN: no GPU work, made-up timings (INVALID as a result)",
+                    "config": {"workload": f"dry run, {N} envs per rank x {world} rank(s)"},
+                    "shards": [czd.shard_range(N * world, world, r) for r in range(world)],
+                    "stats_total_env_steps": sum(e["stats"]["env_steps"] for e in every)}
+            line.update(aggregate(every, K))
+            print(json.dumps(line), flush=True)
+        rdzv.close()
+        return 0
+
+    from cooking_zoo_amd import _native
+    from cooking_zoo_amd.vec_env import CookingVecEnv
     env = CookingVecEnv(count, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"],
                         action_scheme="scheme3", num_layouts=256, layout_seed=0, auto_reset=True,
                         device_id=local_rank, env_id_base=begin)
     L, h = _native.lib(), env._h
     env.reset(return_obs=False)
 
-    # inputs resident in HBM: one int32 [N, A] action tensor per step (uniform over the 5 scheme3 actions);
-    # outputs: obs f64 [N, A, F], rewards f64, terminations / truncations u8
-    chunk = 256
+    # inputs resident in HBM: a ring of int32 [N, A] action tensors, one slot per step (uniform over the 5 scheme3
+    # actions); outputs: obs f64 [N, A, F], rewards f64, terminations / truncations u8.  The ring holds a whole number of
+    # K-step runs so that every timed region replays one of a few graphs of exactly K launches.
+    runs_in_ring = max(1, 256 // K) if K <= 1024 else 1
+    period = K * runs_in_ring if K <= 1024 else 256
     rng = np.random.default_rng(1234 + rank)
-    d_actions = env.alloc((chunk, N, 2), np.int32)
-    d_actions.from_host(rng.integers(0, 5, size=(chunk, N, 2), dtype=np.int32))
+    d_actions = env.alloc((period, N, 2), np.int32)
+    d_actions.from_host(rng.integers(0, 5, size=(period, N, 2), dtype=np.int32))
     d_obs = env.alloc((N, 2, env.F), np.float64)
     d_rew = env.alloc((N, 2), np.float64)
     d_term = env.alloc((N, 2), np.uint8)
     d_trunc = env.alloc((N, 2), np.uint8)
     obs_ptr = None if args.no_obs else d_obs.ptr
+    ring = (d_actions.ptr, N * 2, period)
+    outs = (obs_ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr)
 
-    def run_steps(k, first):
-        # k launches of the step kernel, one per env step, issued from C; step j reads slot (first + j) % chunk of the
-        # action ring (aligned runs of 32 launches are replayed from HIP graphs: cz_step_device_ring)
-        rc = L.cz_step_device_ring(h, k, d_actions.ptr, N * 2, chunk, first % chunk, obs_ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr)
-        if rc:
-            _native.check(h, rc)
+    def run_steps(k, first_slot):
+        # k launches of the step kernel, one per env step, issued from C (cz_step_device_ring: graph replay of the run)
+        _native.check(h, L.cz_step_device_ring(h, k, *ring, first_slot % period, *outs))
 
-    # one-off graph capture outside the measurement (it steps nothing)
-    _native.check(h, L.cz_ring_prepare(h, d_actions.ptr, N * 2, chunk, obs_ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr))
+    def first_slot_of(r):
+        return (r % runs_in_ring) * K if K <= 1024 else 0
+
+    # one-off graph captures outside the measurement (nothing is stepped)
+    if Wm > 0:
+        _native.check(h, L.cz_ring_prepare(h, Wm, *ring, 0, *outs))
+    for r in range(min(R, runs_in_ring)):
+        _native.check(h, L.cz_ring_prepare(h, K, *ring, first_slot_of(r), *outs))
+
+    # ---- the communicator: RCCL over xGMI through the C-ABI, under a deadline (helper thread; every rank learns the outcome)
+    comm_ok, comm_msg = czd.comm_init_with_deadline(env, world, rank, rdzv, COMM_DEADLINE_S)
 
     def barrier():
         env.sync()
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
+        rdzv.barrier()
+        if comm_ok:
+            _native.check(h, L.cz_comm_barrier(h))         # GPU-side: every rank's stream has drained
 
-    run_steps(Wm, 0)
-    barrier()
-    s0 = env.stats()["env_steps"]
-    L.cz_timer_start(h)                                        # HIP event on the stream the kernels run on
-    t0 = time.perf_counter()
-    run_steps(K, Wm)
+    if Wm > 0:
+        run_steps(Wm, 0)
+    L.cz_launch_counts(h, None, None, 1)
+    elapsed, steps_done, kernel_us = [], [], []
     ev_ms = C.c_float()
-    L.cz_timer_stop(h, C.byref(ev_ms))                         # HIP event after the K-th launch, synchronised
-    barrier()
-    elapsed = time.perf_counter() - t0
-    local_env_steps = env.stats()["env_steps"] - s0            # world steps executed (auto-reset passes are not counted)
-
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        cnt = torch.tensor([local_env_steps], dtype=torch.int64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_env_steps = int(cnt.item())
-    else:
-        total_env_steps = local_env_steps
-
-    # the floor of a launch that has to emit this much output: same grid shape, nothing but the stores
-    out_only_us = None
-    if not args.no_obs:
-        us = C.c_float()
-        out_bytes = N * 2 * env.F * 8
-        if L.cz_probe_output_only(h, d_obs.ptr, out_bytes, 500, C.byref(us)) == 0:
-            out_only_us = float(us.value)
-
-    # dominant-kernel duration: HIP events bracket the timed region on the kernels' own stream; the K launches run
-    # back to back (rocprofv3 --kernel-trace shows no gaps, profiles/), so duration = event time / K
-    kernel_us = ev_ms.value * 1e3 / K
-
-    # secondary figure: the same work fused, T steps per launch with the on-device action stream and a trajectory buffer
-    fused = None
-    if not args.no_obs:
-        T = 32
-        d_traj = env.alloc((T, N, 2, env.F), np.float64)
-        d_r = env.alloc((T, N, 2), np.float64)
-        d_te = env.alloc((T, N, 2), np.uint8)
-        d_tr = env.alloc((T, N, 2), np.uint8)
-        reps = max(2, K // T)
-        env.rollout(T, 1, 0, d_traj, d_r, d_te, d_tr)
+    for r in range(R):
+        s0 = env.stats()["env_steps"]
         barrier()
-        f0 = env.stats()["env_steps"]
         t0 = time.perf_counter()
-        for r in range(reps):
-            env.rollout(T, 1, (r + 1) * T, d_traj, d_r, d_te, d_tr)
+        L.cz_timer_start(h)                                    # HIP event on the stream the kernels run on
+        run_steps(K, first_slot_of(r))
+        L.cz_timer_stop(h, C.byref(ev_ms))                     # HIP event after the K-th launch, synchronised
+        env.sync()
+        elapsed.append(time.perf_counter() - t0)
         barrier()
-        dtf = time.perf_counter() - t0
-        fused = {"env_steps_per_s_per_gpu": (env.stats()["env_steps"] - f0) / dtf, "steps_per_launch": T,
-                 "ms_per_step": dtf * 1e3 / (reps * T), "api": "cz_rollout, obs trajectory [T][N][A][F] in HBM"}
-        for b in (d_traj, d_r, d_te, d_tr):
-            b.free()
+        kernel_us.append(ev_ms.value * 1e3 / K)
+        steps_done.append(env.stats()["env_steps"] - s0)       # world steps executed (auto-reset passes are not counted)
+    g_k, d_k = C.c_int64(), C.c_int64()
+    L.cz_launch_counts(h, C.byref(g_k), C.byref(d_k), 0)
 
-    # episode statistics: RCCL all-gather over xGMI of one cz_stats per rank (the path's only collective).
-    # Done twice: through torch.distributed (backend nccl = RCCL) and through the C-ABI's own communicator
-    # (cz_comm_init / cz_stats_allgather); the second runs under a watchdog so that a stuck communicator bring-up on an
-    # unfamiliar node can never cost the timing result.
-    stats_all = None
-    rccl_hung = False
-    if dist is not None:
-        try:
-            per_rank_t = czd.gather_stats_torch(env.stats(), device=torch.device("cuda", local_rank))
-            stats_all = {"via": "torch.distributed nccl", "total": czd.reduce_stats(per_rank_t)}
-        except Exception as exc:                 # keep the timing result even if the stats exchange fails
-            per_rank_t = None
-            stats_all = {"error": str(exc)}
-        box = {}
+    mine = {"elapsed_s": elapsed, "env_steps": steps_done, "kernel_us": kernel_us, "stats": env.stats()}
+    every = [json.loads(b) for b in rdzv.all_gather(json.dumps(mine).encode())]
 
-        def direct():
-            try:
-                torch.cuda.set_device(local_rank)            # the current device is per thread
-                def bcast(payload):
-                    b = [payload]
-                    dist.broadcast_object_list(b, src=0)
-                    return b[0]
-                box["per_rank"] = czd.gather_stats_rccl(env, world, rank, bcast)
-            except Exception as exc:
-                box["error"] = str(exc)
-        th = threading.Thread(target=direct, daemon=True)
-        th.start()
-        th.join(timeout=120.0)
-        flag = torch.tensor([1 if th.is_alive() else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)          # every rank takes the same exit path
-        rccl_hung = bool(flag.item())
-        if th.is_alive():
-            stats_all["cz_stats_allgather"] = "timed out after 120 s (result above is from torch.distributed)"
-        elif "error" in box:
-            stats_all["cz_stats_allgather"] = "failed: " + box["error"]
+    # ---- episode statistics: RCCL all-gather over xGMI of one cz_stats per rank (the path's only collective), checked
+    # against the same structs exchanged over the control plane
+    stats_all = {}
+    rc = 0
+    if comm_ok:
+        done, res = with_deadline(lambda: czd.allgather_stats_rccl(env, world), COMM_DEADLINE_S)
+        if not done:
+            stats_all["cz_stats_allgather"] = f"timed out after {COMM_DEADLINE_S:.0f} s"
+            rc = EXIT_COMM_FAILED
+        elif isinstance(res, Exception):
+            stats_all["cz_stats_allgather"] = "failed: " + str(res)
+            rc = EXIT_COMM_FAILED
         else:
-            same = per_rank_t is not None and box["per_rank"] == per_rank_t
-            stats_all["cz_stats_allgather"] = "ok, identical to the torch.distributed result" if same else "ok"
+            same = res == [e["stats"] for e in every]
+            stats_all["cz_stats_allgather"] = "ok, identical to the control-plane gather" if same else "ok, but DIFFERENT from the control-plane gather"
+            stats_all["total"] = czd.reduce_stats(res)
             if not same:
-                stats_all["total_direct"] = czd.reduce_stats(box["per_rank"])
+                rc = EXIT_COMM_FAILED
+    else:
+        stats_all["cz_stats_allgather"] = "communicator not available: " + comm_msg
+        stats_all["total"] = czd.reduce_stats([e["stats"] for e in every])
+        rc = EXIT_COMM_FAILED
+    flags = [int(b) for b in rdzv.all_gather(str(rc).encode())]     # every rank leaves with the same code
+    rc = max(flags)
 
     if rank == 0:
+        agg = aggregate(every, K)
+        kus = sorted(kernel_us)
+        kernel_med = kus[len(kus) // 2]
+        # the floor of a launch that has to emit this much output: same grid shape, nothing but the stores
+        out_only_us = None
+        if not args.no_obs:
+            us = C.c_float()
+            if L.cz_probe_output_only(h, d_obs.ptr, N * 2 * env.F * 8, 500, C.byref(us)) == 0:
+                out_only_us = float(us.value)
+        # secondary figure: the same work fused, T steps per launch with the on-device action stream and a trajectory buffer
+        fused = None
+        if not args.no_obs:
+            T = 32
+            d_traj = env.alloc((T, N, 2, env.F), np.float64)
+            d_r = env.alloc((T, N, 2), np.float64)
+            d_te = env.alloc((T, N, 2), np.uint8)
+            d_tr = env.alloc((T, N, 2), np.uint8)
+            reps = max(2, min(K, 2000) // T)
+            env.rollout(T, 1, 0, d_traj, d_r, d_te, d_tr)
+            env.sync()
+            f0 = env.stats()["env_steps"]
+            t0 = time.perf_counter()
+            for r in range(reps):
+                env.rollout(T, 1, (r + 1) * T, d_traj, d_r, d_te, d_tr)
+            env.sync()
+            dtf = time.perf_counter() - t0
+            fused = {"env_steps_per_s_per_gpu": (env.stats()["env_steps"] - f0) / dtf, "steps_per_launch": T,
+                     "ms_per_step": dtf * 1e3 / (reps * T), "api": "cz_rollout, obs trajectory [T][N][A][F] in HBM"}
+            for b in (d_traj, d_r, d_te, d_tr):
+                b.free()
+        rccl_path, hip_path = C.create_string_buffer(512), C.create_string_buffer(512)
+        L.cz_runtime_paths(rccl_path, hip_path, 512)
         b_alg = algorithmic_bytes_per_env_step(env)
-        achieved = b_alg * N / (kernel_us * 1e-6) / 1e9
-        value = total_env_steps / elapsed
+        achieved = b_alg * N / (kernel_med * 1e-6) / 1e9
+        total_k = g_k.value + d_k.value
+        api = (f"cz_step_device_ring: one kernel launch per env step; of the {total_k} timed launches {g_k.value} were replayed "
+               f"from HIP graphs of {K if K <= 1024 else 'up to 1024'} launches and {d_k.value} launched directly; "
+               f"actions/obs/rewards/flags resident in HBM")
         line = {
             "metric": "env-steps/sec at N parallel envs (1/2/4/8 GPU) + achieved HBM GB/s",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": agg["value"], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": agg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32 state, f64 obs+reward", "data": "synthetic",
+            "repeats": agg["repeats"], "value_min": agg["value_min"], "value_max": agg["value_max"],
+            "ms_per_step_min": agg["ms_per_step_min"], "ms_per_step_max": agg["ms_per_step_max"],
+            "timing": "median over `repeats` K-step regions, each bracketed by stream sync + all-rank barrier, MAX over ranks per region",
             "config": {"workload": f"{N} envs per GPU x {world} GPU(s), level=coop_test, 2 agents, "
                                    f"recipes=[TomatoLettuceSalad, CarrotBanana], scheme3, max_steps=400, "
                                    f"256-layout pool, on-device auto-reset, feature_vector obs F={env.F} f64, "
                                    f"uniform random actions",
-                       "envs_per_gpu": N, "parallelism": f"env-sharded x{world}, one wavefront per env",
-                       "api": "cz_step_device_ring: one kernel launch per env step (runs of 32 launches replayed from HIP graphs), actions/obs/rewards/flags resident in HBM"},
+                       "envs_per_gpu": N, "parallelism": f"env-sharded x{world}, one wavefront per env, one process per GPU, no torch",
+                       "api": api},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(f"k_step_{N}"),
-                         "kernel": "cz::k_step<1,1,2,3,false> (one wavefront per env, 8 envs per workgroup)", "kernel_us": kernel_us, "alg_bytes_per_env_step": b_alg,
-                         "units_per_launch": N,
+                         "kernel": "cz::k_step<1,1,2,3,false> (one wavefront per env, 8 envs per workgroup)",
+                         "kernel_us": kernel_med, "kernel_us_min": kus[0], "kernel_us_max": kus[-1],
+                         "alg_bytes_per_env_step": b_alg, "units_per_launch": N,
                          # measured on this box, same run: a kernel of the same grid shape that ONLY writes the observation
                          # bytes (write-through 16-byte stores); write-only traffic does not reach the 8 TB/s read+write peak
                          "output_only_launch_us": out_only_us,
-                         "frac_of_output_only_launch": (out_only_us / kernel_us) if out_only_us else None},
-            "achieved_hbm_gbs_end_to_end": b_alg * value / 1e9 / world,
+                         "frac_of_output_only_launch": (out_only_us / kernel_med) if out_only_us else None},
+            "achieved_hbm_gbs_end_to_end": b_alg * agg["value"] / 1e9 / world,
+            "runtime": {"hip": hip_path.value.decode(), "rccl": rccl_path.value.decode(), "torch_imported": "torch" in sys.modules},
+            "episode_stats_allgather": stats_all,
         }
         if fused is not None:
             line["fused_rollout"] = fused
-        if stats_all is not None:
-            line["episode_stats_allgather"] = stats_all
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(env)
         print(json.dumps(line), flush=True)
-    if rccl_hung:
-        os._exit(0)                              # a communicator stuck in bring-up cannot be torn down cleanly
+    try:
+        rdzv.close()
+    except Exception:
+        pass
+    if rc != 0:
+        sys.stdout.flush()
+        os._exit(rc)                             # a communicator stuck in bring-up cannot be torn down: leave, visibly failed
     env.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not started by a launcher: be the launcher.  This process never touches the GPU (it does not even load the
+        # library); every rank is a fresh interpreter that pins its own device.
+        from cooking_zoo_amd.distributed import launch_local
+        sys.exit(launch_local(args.gpus, [os.path.abspath(__file__), *sys.argv[1:]], timeout=3600.0))
+    sys.exit(worker(args))
 
 
 if __name__ == "__main__":

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CZ_LIB", os.path.join(_HERE, "csrc", "libcookingzoo_hip.so"))   # CZ_LIB: diagnostic builds
@@ -55,7 +56,8 @@ SYMBOLS = [
     ("cz_step_device", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     ("cz_step_device_many", C.c_int, [_VP, _I32, _VP, _I64, _I32, _VP, _VP, _VP, _VP]),
     ("cz_step_device_ring", C.c_int, [_VP, _I32, _VP, _I64, _I32, _I32, _VP, _VP, _VP, _VP]),
-    ("cz_ring_prepare", C.c_int, [_VP, _VP, _I64, _I32, _VP, _VP, _VP, _VP]),
+    ("cz_ring_prepare", C.c_int, [_VP, _I32, _VP, _I64, _I32, _I32, _VP, _VP, _VP, _VP]),
+    ("cz_launch_counts", C.c_int, [_VP, C.POINTER(_I64), C.POINTER(_I64), _I32]),
     ("cz_last_marks", C.c_int, [_VP, _VP]),
     ("cz_set_stream", C.c_int, [_VP, _VP]),
     ("cz_probe_output_only", C.c_int, [_VP, _VP, C.c_size_t, _I32, _VP]),
@@ -75,6 +77,8 @@ SYMBOLS = [
     ("cz_comm_unique_id", C.c_int, [_VP]),
     ("cz_comm_init", C.c_int, [_VP, _I32, _I32, _VP]),
     ("cz_stats_allgather", C.c_int, [_VP, _VP]),
+    ("cz_comm_barrier", C.c_int, [_VP]),
+    ("cz_runtime_paths", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
 ]
 
 _lib = None
@@ -82,6 +86,22 @@ _lib = None
 
 class NativeError(RuntimeError):
     pass
+
+
+class _LateTorchGuard:
+    """PyTorch's ROCm wheels bundle their own libamdhip64.so.7 / librccl.so.1 under the SONAMEs of the system libraries
+    this library links.  Loaded after this library, they sit next to the system copies already in use: everything seems
+    to work until the process aborts in a destructor at exit ("double free or corruption", rc 134).  The working order is
+    torch first (both then share torch's runtime), so a first `import torch` that comes too late is refused with an
+    explanation instead.  CZ_ALLOW_LATE_TORCH=1 removes the guard."""
+
+    def find_spec(self, name, path=None, target=None):
+        if name == "torch":
+            raise ImportError("`import torch` after cooking_zoo_amd has loaded libcookingzoo_hip.so: torch's bundled ROCm runtime "
+                              "would be loaded next to the system one already in use and the process would abort at exit. Import "
+                              "torch BEFORE creating the first cooking_zoo_amd environment (see INTEGRATION.md), or set "
+                              "CZ_ALLOW_LATE_TORCH=1 to take the risk.")
+        return None
 
 
 def lib():
@@ -100,6 +120,8 @@ def lib():
         if L.cz_sizeof_config() != C.sizeof(CzConfig) or L.cz_sizeof_stats() != C.sizeof(CzStats):
             raise NativeError("libcookingzoo_hip.so and cooking_zoo_amd/_native.py disagree on struct layouts")
         _lib = L
+        if "torch" not in sys.modules and not os.environ.get("CZ_ALLOW_LATE_TORCH"):
+            sys.meta_path.insert(0, _LateTorchGuard())
     return _lib
 
 

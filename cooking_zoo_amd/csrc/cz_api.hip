@@ -16,25 +16,44 @@
 
 using namespace cz;
 
-// deterministic reduction of the per-env statistics into one cz_stats (fixed thread->env mapping, fixed tree).
+// Deterministic reduction of the per-env statistics into one cz_stats, in two launches.
 // env_steps = finished-episode lengths + steps of the episode in flight + the signed correction word SU_STEPS
 // (steps of episodes aborted by cz_reset, minus what was in flight at cz_reset_stats).
-__global__ __launch_bounds__(256) void k_stats_reduce(const uint32_t *__restrict__ su, const double *__restrict__ sf,
-                                                      const uint32_t *__restrict__ state, int RW, int N, cz_stats *out) {
+// Summation order (fixed, independent of the grid): 256 chains, chain c adds envs c, c + 256, c + 512, ... one after
+// the other; the 256 chain sums are then combined by a fixed binary tree.  Stage 1 spreads the chains over 64
+// single-wave workgroups (4 chains each, 16 lanes per chain: lane j of a chain owns output column j), so the records
+// are pulled in by 64 CUs instead of one; stage 2 is the tree.  Integer columns are exact in any order; the float64
+// columns are bitwise reproducible because the order never changes.
+constexpr int STAT_CHAINS = 256, STAT_COLS = 13;      // columns: 9 integer sums (u64), 4 return sums (f64)
+__global__ __launch_bounds__(64) void k_stats_chains(const uint32_t *__restrict__ su, const double *__restrict__ sf,
+                                                     const uint32_t *__restrict__ state, int RW, int N,
+                                                     unsigned long long *__restrict__ part /* [256][16] */) {
+    const int chain = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 4), col = (int)threadIdx.x & 15;
+    unsigned long long acc = 0;
+    double ret = 0.0;
+#pragma unroll 4
+    for (int e = chain; e < N; e += STAT_CHAINS) {
+        const uint32_t *p = su + (size_t)e * SU_WORDS;
+        if (col == 0) {
+            const uint32_t *rec = state + (size_t)e * RW;
+            const long long steps = (long long)(int)p[SU_STEPS] + (long long)p[SU_LENSUM] + ((rec[W_STATUS] & ST_DONE) ? 0 : (long long)rec[W_T]);
+            acc += (unsigned long long)steps;
+        } else if (col < 5) {
+            const int w = col == 1 ? SU_EPISODES : col == 2 ? SU_LENSUM : col == 3 ? SU_TRUNC : SU_TERM;
+            acc += p[w];
+        } else if (col < 9) {
+            acc += p[SU_COMPLETED0 + col - 5];
+        } else if (col < STAT_COLS) {
+            ret += sf[(size_t)e * SF_WORDS + SF_SUM0 + col - 9];
+        }
+    }
+    part[(size_t)chain * 16 + col] = (col >= 9 && col < STAT_COLS) ? (unsigned long long)__double_as_longlong(ret) : acc;
+}
+__global__ __launch_bounds__(256) void k_stats_tree(const unsigned long long *__restrict__ part, cz_stats *out) {
     __shared__ unsigned long long su64[256][9];
     __shared__ double sd[256][4];
-    unsigned long long acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    double ret[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int e = threadIdx.x; e < N; e += 256) {
-        const uint32_t *p = su + (size_t)e * SU_WORDS;
-        const uint32_t *rec = state + (size_t)e * RW;
-        long long steps = (long long)(int)p[SU_STEPS] + (long long)p[SU_LENSUM] + ((rec[W_STATUS] & ST_DONE) ? 0 : (long long)rec[W_T]);
-        acc[0] += (unsigned long long)steps; acc[1] += p[SU_EPISODES]; acc[2] += p[SU_LENSUM]; acc[3] += p[SU_TRUNC]; acc[4] += p[SU_TERM];
-        for (int a = 0; a < 4; ++a) acc[5 + a] += p[SU_COMPLETED0 + a];
-        for (int a = 0; a < 4; ++a) ret[a] += sf[(size_t)e * SF_WORDS + SF_SUM0 + a];
-    }
-    for (int j = 0; j < 9; ++j) su64[threadIdx.x][j] = acc[j];
-    for (int a = 0; a < 4; ++a) sd[threadIdx.x][a] = ret[a];
+    for (int j = 0; j < 9; ++j) su64[threadIdx.x][j] = part[(size_t)threadIdx.x * 16 + j];
+    for (int a = 0; a < 4; ++a) sd[threadIdx.x][a] = __longlong_as_double((long long)part[(size_t)threadIdx.x * 16 + 9 + a]);
     __syncthreads();
     for (int stride = 128; stride > 0; stride >>= 1) {
         if ((int)threadIdx.x < stride) {
@@ -72,6 +91,15 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_probe_fill(void *dst, uint
         __builtin_amdgcn_raw_buffer_store_b128(u4{0, 0, 0, 0}, rs, off, 0, 16);
 }
 
+// cz_load_layouts with a smaller pool: how many resident records still point past the new pool (layout id or redraw slice)
+__global__ void k_layout_misfits(const uint32_t *__restrict__ state, int RW, int N, uint32_t n_new, unsigned long long *count) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const uint32_t *rec = state + (size_t)e * RW;
+    const uint32_t base = rec[W_POOL] & 0xFFFFu, cnt = rec[W_POOL] >> 16;
+    if (rec[W_LAYOUT] >= n_new || (cnt && base + cnt > n_new)) atomicAdd(count, 1ull);
+}
+
 __global__ void k_count_aborted(uint32_t *su, const uint32_t *__restrict__ state, int RW, long long env_begin, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -94,6 +122,7 @@ struct cz_handle_s {
     uint32_t *d_stat_u = nullptr;
     double *d_stat_f = nullptr;
     cz_stats *d_stats_out = nullptr;
+    unsigned long long *d_stats_part = nullptr;   // [256 chains][16 columns] between the two stages of the reduction
     double *d_lut = nullptr;
     // staging for the host-pointer API
     int32_t *d_actions = nullptr;
@@ -102,7 +131,7 @@ struct cz_handle_s {
     uint32_t *d_marks = nullptr, *marks_out_next = nullptr;   // (cz_step hands the kernel a marks buffer for one launch)
     std::vector<uint32_t> last_marks;          // recipe marks after the most recent cz_step (cz_last_marks)
     char *h_stage = nullptr, *d_stage = nullptr;   // small batches: pinned, device-mapped staging block of cz_step
-    // cz_step_device_ring: replayable graphs of RING_SEG consecutive launches each (one per aligned segment of the ring)
+    // cz_step_device_ring: which ring / output buffers / tables the cached graphs were captured for
     struct RingKey {
         const int32_t *ring = nullptr; int64_t stride = 0; int32_t period = 0;
         double *obs = nullptr, *rew = nullptr; uint8_t *term = nullptr, *trunc = nullptr; hipStream_t stream = nullptr; uint64_t version = 0;
@@ -111,7 +140,10 @@ struct cz_handle_s {
                    trunc == o.trunc && stream == o.stream && version == o.version;
         }
     } ring_key;
-    std::vector<hipGraphExec_t> ring_graphs;
+    struct RunGraph { int32_t slot, len; hipGraphExec_t ge; uint64_t used; };
+    std::vector<RunGraph> ring_graphs;             // replayable runs of this ring, keyed by (first slot, length)
+    uint64_t ring_clock = 0;
+    int64_t n_graph_kernels = 0, n_direct_kernels = 0;
     uint64_t tables_version = 0;                   // bumped whenever something the launches capture by value changes
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // kernel timing
@@ -150,7 +182,7 @@ static int fail(cz_handle h, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *cz_last_error(cz_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
-extern "C" int32_t cz_abi_version(void) { return 1; }
+extern "C" int32_t cz_abi_version(void) { return 2; }
 // diagnostic builds only (tools/phase_profile.py): where the kernels write their s_memtime stamps
 extern "C" int cz_debug_set_stamps(cz_handle h, void *d_buf) {
     if (!h) return 1;
@@ -237,6 +269,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     CREATE_CHK(hipMemsetAsync(h->d_stat_u, 0, N * SU_WORDS * 4, h->stream));
     CREATE_CHK(hipMemsetAsync(h->d_stat_f, 0, N * SF_WORDS * 8, h->stream));
     CREATE_CHK(hipMalloc(&h->d_stats_out, sizeof(cz_stats)));
+    CREATE_CHK(hipMalloc(&h->d_stats_part, (size_t)STAT_CHAINS * 16 * sizeof(unsigned long long)));
     CREATE_CHK(hipStreamSynchronize(h->stream));
     P.state = h->d_state; P.stat_u = h->d_stat_u; P.stat_f = h->d_stat_f;
     {   // observation quotients: (x - ax) / W and (y - ay) / H for every possible difference, computed here with the same
@@ -271,12 +304,12 @@ extern "C" int cz_destroy(cz_handle h) {
         destroy_t f = (destroy_t)dlsym(h->rccl, "ncclCommDestroy");
         if (f) f(h->comm);
     }
-    void *ptrs[] = {h->d_lut, h->d_state, h->d_lay_init, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out,
+    void *ptrs[] = {h->d_lut, h->d_state, h->d_lay_init, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out, h->d_stats_part,
                     h->d_actions, h->d_obs, h->d_rew, h->d_term, h->d_trunc, h->d_gather, h->d_marks};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    for (hipGraphExec_t g : h->ring_graphs)
-        if (g) (void)hipGraphExecDestroy(g);
+    for (auto &r : h->ring_graphs)
+        if (r.ge) (void)hipGraphExecDestroy(r.ge);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     for (hipEvent_t e : h->kev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -381,6 +414,21 @@ extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const 
     }
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->n_layouts > 0 && n < h->n_layouts) {
+        // a smaller pool: the kernels index lay_desc / lay_init with the layout id and the redraw slice of every resident
+        // record, so records that point past the new pool would read out of bounds on the next step / observe / auto-reset
+        unsigned long long misfits = 0;
+        HIPCHK(h, hipMemsetAsync(h->d_stats_part, 0, sizeof misfits, h->stream));
+        hipLaunchKernelGGL(k_layout_misfits, dim3((unsigned)((h->P.N + 255) / 256)), dim3(256), 0, h->stream, h->d_state, h->P.RW, h->P.N,
+                           (uint32_t)n, h->d_stats_part);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(&misfits, h->d_stats_part, sizeof misfits, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (misfits)
+            return fail(h, "cz_load_layouts: %llu resident env record(s) refer to layouts >= %d of the pool being replaced (%d layouts); "
+                           "cz_reset / cz_set_state them into the new range first, or load a pool that is not smaller",
+                        misfits, n, h->n_layouts);
+    }
     if (h->d_lay_init) { HIPCHK(h, hipFree(h->d_lay_init)); h->d_lay_init = nullptr; h->P.lay_init = nullptr; }
     if (h->d_lay_desc) { HIPCHK(h, hipFree(h->d_lay_desc)); h->d_lay_desc = nullptr; h->P.lay_desc = nullptr; }
     size_t b0 = (size_t)n * h->P.RW * 4, b1 = (size_t)n * h->P.F * 4;
@@ -524,11 +572,10 @@ extern "C" int cz_observe(cz_handle h, int64_t b, int64_t c, double *obs) {
 }
 
 static int set_device(cz_handle h) {
-    static thread_local int current = -1;          // hipSetDevice is not free: only when the calling thread switches GPUs
-    if (current != h->cfg.device_id) {
-        HIPCHK(h, hipSetDevice(h->cfg.device_id));
-        current = h->cfg.device_id;
-    }
+    // hipSetDevice is not free, hipGetDevice is: switch only when the calling thread is on another GPU (the caller, or
+    // another handle, may have changed the thread's current device since the last call)
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->cfg.device_id) HIPCHK(h, hipSetDevice(h->cfg.device_id));
     return 0;
 }
 
@@ -561,17 +608,19 @@ extern "C" int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_acti
 }
 
 // The same K launches for callers that keep their actions in a ring of `period` slots (slot s at d_ring + s * stride):
-// step k reads slot (first_slot + k) % period.  Aligned runs of RING_SEG slots are captured once into a graph and
-// replayed afterwards, which takes the host out of the loop (0.02 us instead of ~2.5 us of CPU per launch) and lets the
-// kernels read their arguments from memory that is not rewritten before every launch.  Everything else is launched
-// directly; results are identical to cz_step_device_many.
-constexpr int RING_SEG = 32;
-// captures the launches of slots [slot, slot + RING_SEG) (nothing executes) and instantiates them
-static int ring_capture(cz_handle h, Params &P, const int32_t *d_ring, int64_t stride, int32_t slot, hipGraphExec_t &ge) {
+// step k reads slot (first_slot + k) % period.  A run of consecutive slots is captured once into a HIP graph, keyed by
+// (first slot, length), and replayed afterwards: that takes the host out of the loop (0.02 us instead of ~2.5 us of CPU
+// per launch) and the kernels read their arguments from memory that is not rewritten before every launch.  A run is cut
+// where the ring wraps and at RING_MAX_GRAPH launches; pieces shorter than RING_MIN_GRAPH are launched directly.  At
+// most RING_CACHE graphs are kept (least recently used goes first), so a caller that keeps asking for new (slot, length)
+// pairs pays a capture each time -- keep the runs of a loop aligned.  Results are identical to cz_step_device_many.
+constexpr int RING_MIN_GRAPH = 4, RING_MAX_GRAPH = 1024, RING_CACHE = 64;
+// captures the launches of slots [slot, slot + len) (nothing executes) and instantiates them
+static int ring_capture(cz_handle h, Params &P, const int32_t *d_ring, int64_t stride, int32_t slot, int32_t len, hipGraphExec_t &ge) {
     hipGraph_t g = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     int bad = 0;
-    for (int s = 0; s < RING_SEG && !bad; ++s) {
+    for (int s = 0; s < len && !bad; ++s) {
         P.actions = d_ring + (int64_t)(slot + s) * stride;
         bad = launch_step(h, P);
     }
@@ -585,56 +634,91 @@ static int ring_capture(cz_handle h, Params &P, const int32_t *d_ring, int64_t s
 }
 static bool ring_select(cz_handle h, const int32_t *d_ring, int64_t stride, int32_t period, double *d_obs, double *d_rewards,
                         uint8_t *d_term, uint8_t *d_trunc) {
-    if (h->ktime || !h->graphs_enabled || period % RING_SEG != 0) return false;
+    if (h->ktime || !h->graphs_enabled) return false;
     cz_handle_s::RingKey key;
     key.ring = d_ring; key.stride = stride; key.period = period; key.obs = d_obs; key.rew = d_rewards; key.term = d_term;
     key.trunc = d_trunc; key.stream = h->stream; key.version = h->tables_version;
-    if (!(key == h->ring_key)) {
-        for (hipGraphExec_t g : h->ring_graphs)
-            if (g) (void)hipGraphExecDestroy(g);
-        h->ring_graphs.assign((size_t)(period / RING_SEG), nullptr);
+    if (!(key == h->ring_key)) {                   // another ring, other output buffers or new tables: every graph is stale
+        if (!h->ring_graphs.empty()) (void)hipStreamSynchronize(h->stream);
+        for (auto &r : h->ring_graphs)
+            if (r.ge) (void)hipGraphExecDestroy(r.ge);
+        h->ring_graphs.clear();
         h->ring_key = key;
     }
     return true;
 }
-// Builds every graph cz_step_device_ring would build lazily for this ring and these output buffers, without stepping
-// anything (so that a measurement does not pay the one-off capture inside its timed region).
-extern "C" int cz_ring_prepare(cz_handle h, const int32_t *d_ring, int64_t stride, int32_t period, double *d_obs, double *d_rewards,
-                               uint8_t *d_term, uint8_t *d_trunc) {
-    if (ready(h)) return 1;
-    if (!d_ring || period < 1) return fail(h, "cz_ring_prepare: bad arguments");
-    if (set_device(h)) return 1;
-    if (!ring_select(h, d_ring, stride, period, d_obs, d_rewards, d_term, d_trunc)) return 0;
-    Params P = h->P;
-    P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
-    for (int32_t slot = 0; slot < period; slot += RING_SEG) {
-        hipGraphExec_t &ge = h->ring_graphs[(size_t)(slot / RING_SEG)];
-        if (!ge && ring_capture(h, P, d_ring, stride, slot, ge)) return 1;
+// the graph of run [slot, slot + len), captured on first use
+static int ring_graph(cz_handle h, Params &P, const int32_t *d_ring, int64_t stride, int32_t slot, int32_t len, hipGraphExec_t &out) {
+    h->ring_clock++;
+    for (auto &r : h->ring_graphs)
+        if (r.slot == slot && r.len == len) { r.used = h->ring_clock; out = r.ge; return 0; }
+    if ((int)h->ring_graphs.size() >= RING_CACHE) {
+        size_t victim = 0;
+        for (size_t i = 1; i < h->ring_graphs.size(); ++i)
+            if (h->ring_graphs[i].used < h->ring_graphs[victim].used) victim = i;
+        HIPCHK(h, hipStreamSynchronize(h->stream));            // it may still be executing
+        (void)hipGraphExecDestroy(h->ring_graphs[victim].ge);
+        h->ring_graphs.erase(h->ring_graphs.begin() + (long)victim);
     }
+    hipGraphExec_t ge = nullptr;
+    if (ring_capture(h, P, d_ring, stride, slot, len, ge)) return 1;
+    h->ring_graphs.push_back({slot, len, ge, h->ring_clock});
+    out = ge;
     return 0;
 }
-extern "C" int cz_step_device_ring(cz_handle h, int32_t K, const int32_t *d_ring, int64_t stride, int32_t period, int32_t first_slot,
-                                   double *d_obs, double *d_rewards, uint8_t *d_term, uint8_t *d_trunc) {
-    if (ready(h)) return 1;
-    if (!d_ring || K < 1 || period < 1 || first_slot < 0 || first_slot >= period) return fail(h, "cz_step_device_ring: bad arguments");
-    if (set_device(h)) return 1;
+// walks the run [first_slot, first_slot + K) piece by piece; launch = false only builds the graphs
+static int ring_walk(cz_handle h, int32_t K, const int32_t *d_ring, int64_t stride, int32_t period, int32_t first_slot, double *d_obs,
+                     double *d_rewards, uint8_t *d_term, uint8_t *d_trunc, bool launch) {
     Params P = h->P;
     P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
     const bool graphs = ring_select(h, d_ring, stride, period, d_obs, d_rewards, d_term, d_trunc);
     int32_t k = 0;
     while (k < K) {
         const int32_t slot = (int32_t)(((int64_t)first_slot + k) % period);
-        if (graphs && slot % RING_SEG == 0 && K - k >= RING_SEG) {
-            hipGraphExec_t &ge = h->ring_graphs[(size_t)(slot / RING_SEG)];
-            if (!ge && ring_capture(h, P, d_ring, stride, slot, ge)) return 1;
-            HIPCHK(h, hipGraphLaunch(ge, h->stream));
-            k += RING_SEG;
-        } else {
-            P.actions = d_ring + (int64_t)slot * stride;
-            if (launch_step(h, P)) return 1;
-            k += 1;
+        int32_t run = K - k;
+        if (run > period - slot) run = period - slot;
+        if (run > RING_MAX_GRAPH) run = RING_MAX_GRAPH;
+        if (graphs && run >= RING_MIN_GRAPH) {
+            hipGraphExec_t ge = nullptr;
+            if (ring_graph(h, P, d_ring, stride, slot, run, ge)) return 1;
+            if (launch) {
+                HIPCHK(h, hipGraphLaunch(ge, h->stream));
+                h->n_graph_kernels += run;
+            }
+        } else if (launch) {
+            for (int32_t j = 0; j < run; ++j) {
+                P.actions = d_ring + (int64_t)(slot + j) * stride;
+                if (launch_step(h, P)) return 1;
+            }
+            h->n_direct_kernels += run;
         }
+        k += run;
     }
+    return 0;
+}
+// Builds every graph cz_step_device_ring(K, ..., first_slot, ...) would build lazily, without stepping anything (so that a
+// measurement does not pay the one-off capture inside its timed region).
+extern "C" int cz_ring_prepare(cz_handle h, int32_t K, const int32_t *d_ring, int64_t stride, int32_t period, int32_t first_slot,
+                               double *d_obs, double *d_rewards, uint8_t *d_term, uint8_t *d_trunc) {
+    if (ready(h)) return 1;
+    if (!d_ring || K < 1 || period < 1 || first_slot < 0 || first_slot >= period) return fail(h, "cz_ring_prepare: bad arguments");
+    if (set_device(h)) return 1;
+    return ring_walk(h, K, d_ring, stride, period, first_slot, d_obs, d_rewards, d_term, d_trunc, false);
+}
+extern "C" int cz_step_device_ring(cz_handle h, int32_t K, const int32_t *d_ring, int64_t stride, int32_t period, int32_t first_slot,
+                                   double *d_obs, double *d_rewards, uint8_t *d_term, uint8_t *d_trunc) {
+    if (ready(h)) return 1;
+    if (!d_ring || K < 1 || period < 1 || first_slot < 0 || first_slot >= period) return fail(h, "cz_step_device_ring: bad arguments");
+    if (set_device(h)) return 1;
+    return ring_walk(h, K, d_ring, stride, period, first_slot, d_obs, d_rewards, d_term, d_trunc, true);
+}
+// how many step kernels of this handle were replayed from graphs / launched directly (cz_step_device_ring only);
+// reset != 0 zeroes the counters after reading
+extern "C" int cz_launch_counts(cz_handle h, int64_t *graph_kernels, int64_t *direct_kernels, int32_t reset) {
+    if (!h) return fail(nullptr, "null handle");
+    if (graph_kernels) *graph_kernels = h->n_graph_kernels;
+    if (direct_kernels) *direct_kernels = h->n_direct_kernels;
+    if (reset) h->n_graph_kernels = h->n_direct_kernels = 0;
     return 0;
 }
 
@@ -654,6 +738,13 @@ extern "C" int cz_step(cz_handle h, const int32_t *actions, double *obs, double 
     if (!actions || !rewards || !term || !trunc) return fail(h, "cz_step: null buffer");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const size_t NA = (size_t)h->P.N * h->P.A;
+    {   // host actions are checked here (the device-pointer entry points cannot look: their kernel reads action & 7)
+        const int32_t n_actions = h->P.scheme == 3 ? 5 : 8;              // actions.py:17,50
+        for (size_t i = 0; i < NA; ++i)
+            if (actions[i] >= n_actions)
+                return fail(h, "cz_step: action %d of env %zu, agent %zu is outside [0, %d) (negative = despawned)", actions[i],
+                            i / (size_t)h->P.A, i % (size_t)h->P.A, n_actions);
+    }
     const size_t ob = NA * h->P.F * 8;
     // Small batches (the single-env facade): the step is pure latency, so the kernel reads the actions from and writes
     // its outputs to one pinned, device-mapped host block -- one launch and one synchronisation, no copy commands.
@@ -795,11 +886,17 @@ extern "C" int cz_kernel_time_read(cz_handle h, double *total_ms, int64_t *launc
 }
 
 // ---- statistics + RCCL ----------------------------------------------------------------------------------
+static int stats_reduce(cz_handle h) {
+    hipLaunchKernelGGL(k_stats_chains, dim3(STAT_CHAINS / 4), dim3(64), 0, h->stream, h->d_stat_u, h->d_stat_f, h->d_state, h->P.RW, h->P.N,
+                       h->d_stats_part);
+    hipLaunchKernelGGL(k_stats_tree, dim3(1), dim3(256), 0, h->stream, h->d_stats_part, h->d_stats_out);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
 extern "C" int cz_get_stats(cz_handle h, cz_stats *out) {
     if (!h || !out) return fail(h, "cz_get_stats: null argument");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(256), 0, h->stream, h->d_stat_u, h->d_stat_f, h->d_state, h->P.RW, h->P.N, h->d_stats_out);
-    HIPCHK(h, hipGetLastError());
+    if (stats_reduce(h)) return 1;
     HIPCHK(h, hipMemcpyAsync(out, h->d_stats_out, sizeof(cz_stats), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -817,11 +914,34 @@ extern "C" int cz_reset_stats(cz_handle h) {
 // RCCL is loaded lazily so that the library also loads on machines without it (CPU build check)
 typedef struct { char internal[128]; } cz_nccl_id;
 static void *rccl_lib(cz_handle h) {
+    // One process holds one RCCL.  A copy that is already loaded (e.g. the librccl.so.1 a PyTorch wheel bundles, loaded
+    // together with the HIP runtime that copy was built against) must be the one that is used: glibc matches loaded
+    // objects by SONAME, so ask for the SONAME first and without loading anything (RTLD_NOLOAD), then load by SONAME,
+    // then by the development name.
     static void *lib = nullptr;
-    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) fail(h, "cannot load librccl.so: %s", dlerror());
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) fail(h, "cannot load librccl.so.1 / librccl.so: %s", dlerror());
     return lib;
+}
+// which files serve this process: the RCCL the communicator binds and the HIP runtime the library runs on (diagnostics
+// for mixed-stack problems; bench.py prints both)
+extern "C" int cz_runtime_paths(char *rccl_path, char *hip_path, size_t cap) {
+    if (rccl_path && cap) {
+        rccl_path[0] = 0;
+        if (void *lib = rccl_lib(nullptr)) {
+            Dl_info info;
+            void *sym = dlsym(lib, "ncclGetUniqueId");
+            if (sym && dladdr(sym, &info) && info.dli_fname) snprintf(rccl_path, cap, "%s", info.dli_fname);
+        }
+    }
+    if (hip_path && cap) {
+        hip_path[0] = 0;
+        Dl_info info;
+        if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) snprintf(hip_path, cap, "%s", info.dli_fname);
+    }
+    return 0;
 }
 extern "C" int cz_comm_unique_id(uint8_t id[128]) {
     void *lib = rccl_lib(nullptr);
@@ -857,14 +977,31 @@ extern "C" int cz_stats_allgather(cz_handle h, cz_stats *out) {
     if (!h || !out) return fail(h, "cz_stats_allgather: null argument");
     if (!h->comm) return fail(h, "cz_stats_allgather: communicator not initialised (cz_comm_init)");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(256), 0, h->stream, h->d_stat_u, h->d_stat_f, h->d_state, h->P.RW, h->P.N, h->d_stats_out);
-    HIPCHK(h, hipGetLastError());
+    if (stats_reduce(h)) return 1;
     typedef int (*fn_t)(const void *, void *, size_t, int, void *, hipStream_t);
     fn_t f = (fn_t)dlsym(h->rccl, "ncclAllGather");
     if (!f) return fail(h, "ncclAllGather not found");
     int r = f(h->d_stats_out, h->d_gather, sizeof(cz_stats), /*ncclInt8*/ 0, h->comm, h->stream);
     if (r) return fail(h, "ncclAllGather failed: %d", r);
     HIPCHK(h, hipMemcpyAsync(out, h->d_gather, sizeof(cz_stats) * (size_t)h->n_ranks, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// Barrier over the communicator: a 4-byte RCCL all-reduce on the handle's stream, then a stream synchronisation.  Every
+// rank returns only after every rank's earlier work on its handle stream has finished (bench.py brackets its timed
+// region with it).
+extern "C" int cz_comm_barrier(cz_handle h) {
+    if (!h) return fail(nullptr, "null handle");
+    if (!h->comm) return fail(h, "cz_comm_barrier: communicator not initialised (cz_comm_init)");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    typedef int (*fn_t)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    fn_t f = (fn_t)dlsym(h->rccl, "ncclAllReduce");
+    if (!f) return fail(h, "ncclAllReduce not found");
+    // d_gather holds n_ranks cz_stats: its first word doubles as the barrier token (overwritten by the next all-gather)
+    HIPCHK(h, hipMemsetAsync(h->d_gather, 0, 4, h->stream));
+    int r = f(h->d_gather, h->d_gather, 1, /*ncclInt32*/ 2, /*ncclSum*/ 0, h->comm, h->stream);
+    if (r) return fail(h, "ncclAllReduce failed: %d", r);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }

@@ -191,6 +191,8 @@ class CookingVecEnv:
         """actions int [N, A] -> (obs f64 [N, A, F] | None, rewards f64 [N, A], terminations u8, truncations u8).
         An action of -1 means "this agent is despawned": it is left out of the step (cooking_world.py:105-108)."""
         acts = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.num_envs, self.num_agents)
+        if acts.size and int(acts.max()) >= self.n_actions:
+            raise ValueError(f"actions must be in [0, {self.n_actions}) for {self.action_scheme} (negative = despawned agent)")
         N, A = self.num_envs, self.num_agents
         obs = np.empty((N, A, self.F), dtype=np.float64) if return_obs else None
         rew = np.empty((N, A), dtype=np.float64)

@@ -132,14 +132,20 @@ int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_actions, int64_
                         double *d_obs, double *d_rewards, uint8_t *d_terminations, uint8_t *d_truncations);
 
 /* The same for actions kept in a ring of `action_period` slots (slot s at d_ring + s * action_stride): step k reads slot
- * (first_slot + k) % action_period.  Aligned runs of 32 slots are captured into HIP graphs on first use and replayed
- * afterwards (no host work per launch, stable kernel-argument memory); identical results. */
+ * (first_slot + k) % action_period.  Runs of consecutive slots (cut where the ring wraps and at 1024 launches; at least
+ * 4 launches long) are captured into HIP graphs on first use, keyed by (first slot, length), and replayed afterwards
+ * (no host work per launch, stable kernel-argument memory); shorter pieces are launched directly; identical results.
+ * At most 64 graphs are kept per handle: keep the runs of a loop aligned to the same slots. */
 int cz_step_device_ring(cz_handle h, int32_t K, const int32_t *d_ring, int64_t action_stride, int32_t action_period,
                         int32_t first_slot, double *d_obs, double *d_rewards, uint8_t *d_terminations, uint8_t *d_truncations);
 
-/* Optional: build all graphs of a ring up front (nothing is stepped), e.g. before a timed region. */
-int cz_ring_prepare(cz_handle h, const int32_t *d_ring, int64_t action_stride, int32_t action_period, double *d_obs,
-                    double *d_rewards, uint8_t *d_terminations, uint8_t *d_truncations);
+/* Optional: build the graphs of one such call up front (nothing is stepped), e.g. before a timed region. */
+int cz_ring_prepare(cz_handle h, int32_t K, const int32_t *d_ring, int64_t action_stride, int32_t action_period,
+                    int32_t first_slot, double *d_obs, double *d_rewards, uint8_t *d_terminations, uint8_t *d_truncations);
+
+/* How many step kernels cz_step_device_ring has replayed from graphs / launched directly on this handle so far
+ * (reset != 0: zero both after reading).  bench.py describes its run from these numbers. */
+int cz_launch_counts(cz_handle h, int64_t *graph_kernels, int64_t *direct_kernels, int32_t reset);
 
 /* T fused steps in one launch with on-device uniform random actions (counter-based stream keyed by
  * (seed, global env id, agent, step0 + t)); state stays in registers between steps.  d_obs, if not NULL,
@@ -175,6 +181,11 @@ int cz_reset_stats(cz_handle h);
 int cz_comm_unique_id(uint8_t id[128]);
 int cz_comm_init(cz_handle h, int32_t n_ranks, int32_t rank, const uint8_t id[128]);
 int cz_stats_allgather(cz_handle h, cz_stats *out /* [n_ranks] */);
+/* barrier over the communicator (a 4-byte all-reduce on the handle's stream + stream synchronisation) */
+int cz_comm_barrier(cz_handle h);
+/* diagnostics: the files that serve this process -- the RCCL library the communicator binds (a copy already loaded in
+ * the process wins) and the HIP runtime this library runs on; each buffer holds `cap` bytes, either may be NULL */
+int cz_runtime_paths(char *rccl_path, char *hip_path, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,104 @@
+"""The torch-free multi-rank path of bench.py on a machine without GPUs: `python bench.py --gpus 2 --dry-run` makes the
+parent start two fresh rank processes (cooking_zoo_amd.distributed.launch_local), the ranks meet through the tmpfs
+rendezvous directory, exchange their (made-up) timings, and rank 0 prints the aggregated line: whole-job throughput =
+sum of the ranks' env-steps / the slowest rank's time, per timed region, median over the regions."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+import threading
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def _run_bench(*extra, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "CZ_RDZV_DIR"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *extra], capture_output=True, text=True, env=e, timeout=180)
+    return p
+
+
+def test_gpus_flag_spawns_ranks_and_aggregates():
+    p = _run_bench("--gpus", "2", "--dry-run", "--steps", "20", "--warmup", "5", "--repeats", "5", "--envs", "64")
+    assert p.returncode == 0, p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                      # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["repeats"] == 5
+    assert d["shards"] == [[0, 64], [64, 64]]
+    # dry-run timings: rank r, region i takes 1e-3 * (r + 1 + 0.01 i) s and "does" K * envs env-steps
+    per_region = [2 * 20 * 64 / (1e-3 * (2 + 0.01 * i)) for i in range(5)]       # slowest rank = rank 1
+    assert d["value"] == pytest.approx(sorted(per_region)[2])
+    assert d["value_max"] == pytest.approx(max(per_region)) and d["value_min"] == pytest.approx(min(per_region))
+    assert d["ms_per_step"] == pytest.approx(sorted(1e-3 * (2 + 0.01 * i) * 1e3 / 20 for i in range(5))[2])
+    assert d["stats_total_env_steps"] == 2 * 20 * 64 * 5
+    assert "DRY RUN" in d["data"]
+
+
+def test_single_rank_goes_through_the_same_path():
+    p = _run_bench("--gpus", "1", "--dry-run", "--steps", "8", "--warmup", "0", "--repeats", "4", "--envs", "16")
+    assert p.returncode == 0, p.stderr
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["shards"] == [[0, 16]] and d["repeats"] == 4
+
+
+def test_launcher_env_is_honoured_like_torchrun():
+    """Started by an external launcher (RANK / WORLD_SIZE set, no CZ_RDZV_DIR): the ranks derive the same directory."""
+    import tempfile
+    d = tempfile.mkdtemp(prefix="cz_t_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    procs = []
+    for r in range(2):
+        e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", CZ_RDZV_DIR=d)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "10",
+                                       "--repeats", "3", "--envs", "8"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert outs[0][0].count("{") >= 1 and outs[1][0].strip() == ""          # only rank 0 prints
+    assert json.loads(outs[0][0].splitlines()[-1])["n_gpus"] == 2
+
+
+def test_launch_local_propagates_failure_and_kills_the_rest(tmp_path):
+    from cooking_zoo_amd.distributed import launch_local
+    script = tmp_path / "child.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, time
+        if os.environ["RANK"] == "1":
+            sys.exit(7)
+        time.sleep(600)
+    """))
+    import time
+    t0 = time.monotonic()
+    assert launch_local(3, [str(script)], timeout=60.0) == 7
+    assert time.monotonic() - t0 < 30
+
+
+def test_launch_local_deadline(tmp_path):
+    from cooking_zoo_amd.distributed import launch_local
+    script = tmp_path / "child.py"
+    script.write_text("import time; time.sleep(600)\n")
+    assert launch_local(2, [str(script)], timeout=1.0) == 124
+
+
+def test_file_rendezvous_collectives_and_timeout(tmp_path):
+    from cooking_zoo_amd.distributed import FileRendezvous, RendezvousTimeout
+    world = 3
+    got = {}
+
+    def rank_main(r):
+        rv = FileRendezvous(str(tmp_path / "rv"), r, world, timeout=20.0)
+        got[r] = (rv.all_gather(f"hello {r}".encode()), rv.broadcast(b"id-bytes" if r == 0 else None), rv.broadcast(b"x" if r == 2 else None, src=2))
+        rv.barrier()
+    ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    for r in range(world):
+        assert got[r] == ([b"hello 0", b"hello 1", b"hello 2"], b"id-bytes", b"x")
+    lonely = FileRendezvous(str(tmp_path / "rv2"), 0, 2, timeout=0.3)
+    with pytest.raises(RendezvousTimeout):
+        lonely.barrier()

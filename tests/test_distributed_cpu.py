@@ -72,7 +72,7 @@ def _worker(rank, world, port, total, T, seed, q):
 
 
 def test_two_rank_shards_equal_single_process():
-    import torch.multiprocessing as mp
+    import multiprocessing as mp          # (stdlib: the parent never imports torch; the spawned ranks do)
     from cooking_zoo_amd import distributed as czd
     total, T, seed, world = 22, 45, 77, 2
     ctx = mp.get_context("spawn")

@@ -1,0 +1,188 @@
+"""GPU: the BASELINE configurations at their FULL sizes against the oracle, and both observation-store flavours.
+
+* `launch_step` (cz_api.hip) picks plain `global_store` instead of write-through buffer stores for the observation of
+  the one-launch-per-step kernel once N*A*F*8 exceeds 128 MiB -- above ~30 k envs for config 2, ~5 k for config 5.  The
+  small-batch tests never reach that branch, so it is pinned here twice: by forcing either flavour on small batches of
+  every level family (CZ_WT=0/1, read at cz_create) and by running configs 3, 4 (one rank's shard) and 5 at full size.
+* The oracle runs threaded (tests/oracle_binding.ShardedOracle); every comparison is bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from cooking_zoo_amd import soa
+
+pytestmark = pytest.mark.gpu
+
+BOOK = ["TomatoSalad", "TomatoLettuceSalad", "TomatoLettuceOnionSalad", "CarrotBanana", "MashedCarrotBanana",
+        "CucumberOnion", "AppleWatermelon", "no_recipe"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def strip(recs):
+    r = recs.copy()
+    r[:, soa.RET_WORD0:soa.RET_WORD0 + 8] = 0
+    return r
+
+
+def make(n, level, meta, agents, recipes, scheme="scheme3", **kw):
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    args = dict(max_steps=30, num_layouts=16, auto_reset=True)
+    args.update(kw)
+    ms = args.pop("max_steps")
+    return CookingVecEnv(n, level, meta, agents, ms, recipes, action_scheme=scheme, **args)
+
+
+FAMILIES = [
+    ("coop_test", "example", 1, ["TomatoLettuceSalad"], "scheme3"),
+    ("coop_test", "example", 2, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3"),
+    ("switch_test", "example", 2, ["MashedCarrotBanana", "TomatoSalad"], "scheme1"),
+    ("coexistence_test", "example", 2, ["AppleWatermelon", "TomatoLettuceOnionSalad"], "scheme3"),
+    ("crowded_6x5", "crowded_6x5", 3, ["TomatoSalad", "no_recipe", "MashedCarrotBanana"], "scheme3"),
+    ("crowded_6x5", "crowded_6x5", 4, ["TomatoSalad", "TomatoLettuceSalad", "no_recipe", "MashedCarrotBanana"], "scheme1"),
+    ("edge_8x8", "edge", 3, ["TomatoSalad", "MashedCarrotBanana", "TomatoLettuceSalad"], "scheme3"),
+    ("edge_9x8", "edge", 1, ["TomatoSalad"], "scheme1"),
+    ("large_16x16", "large_16x16", 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"], "scheme3"),
+    ("dense_16x16", "dense_16x16", 2, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3"),
+    ("limit_32x8", "limits", 2, ["TomatoSalad", "CarrotBanana"], "scheme3"),
+    ("limit_8x31", "limits", 3, ["TomatoSalad", "CarrotBanana", "AppleWatermelon"], "scheme1"),
+]
+
+
+@pytest.mark.parametrize("wt", [0, 1])
+@pytest.mark.parametrize("level,meta,agents,recipes,scheme", FAMILIES)
+def test_both_store_flavours_match_oracle(wt, level, meta, agents, recipes, scheme):
+    from oracle_binding import VecOracle
+    n, T = 80, 45
+    os.environ["CZ_WT"] = str(wt)
+    try:
+        env = make(n, level, meta, agents, recipes, scheme, max_steps=20, num_layouts=6)
+    finally:
+        del os.environ["CZ_WT"]
+    orc = VecOracle.from_vec_env(env)
+    assert np.array_equal(bits(env.reset()), bits(orc.reset()))
+    rng = np.random.default_rng(11 + wt)
+    d_act = env.alloc((n, agents), np.int32)
+    d_obs = env.alloc((n, agents, env.F), np.float64)
+    d_rew = env.alloc((n, agents), np.float64)
+    d_t = env.alloc((n, agents), np.uint8)
+    d_u = env.alloc((n, agents), np.uint8)
+    for t in range(T):
+        acts = rng.integers(0, env.n_actions, size=(n, agents), dtype=np.int32)
+        d_act.from_host(acts)
+        env.step_device(d_act, d_obs, d_rew, d_t, d_u)              # the device-pointer path the bench uses
+        env.sync()
+        oo, ro, to, uo = orc.step(acts)
+        assert np.array_equal(bits(d_obs.to_host()), bits(oo)), f"obs @ step {t} (wt={wt})"
+        assert np.array_equal(bits(d_rew.to_host()), bits(ro)), f"rewards @ step {t}"
+        assert np.array_equal(d_t.to_host(), to) and np.array_equal(d_u.to_host(), uo), f"flags @ step {t}"
+    assert np.array_equal(strip(env.get_state()), orc.records)
+    env.close()
+
+
+def _full_size_case(env, steps, T_fused, seed):
+    """`steps` one-launch-per-step launches with external actions (every output compared at every step), then one fused
+    rollout of T_fused steps (final records, last observation, last rewards / flags compared)."""
+    from oracle_binding import ShardedOracle
+    n, A = env.num_envs, env.num_agents
+    orc = ShardedOracle(env)
+    og = env.reset()
+    assert np.array_equal(bits(og), bits(orc.reset())), "reset observation"
+    del og
+    rng = np.random.default_rng(seed)
+    for t in range(steps):
+        acts = rng.integers(0, env.n_actions, size=(n, A), dtype=np.int32)
+        og, rg, tg, ug = env.step(acts)
+        oo, ro, to, uo = orc.step(acts)
+        assert np.array_equal(bits(rg), bits(ro)), f"rewards @ step {t}"
+        assert np.array_equal(tg, to) and np.array_equal(ug, uo), f"flags @ step {t}"
+        assert np.array_equal(bits(og), bits(oo)), f"obs @ step {t}"
+        del og, oo
+    assert np.array_equal(strip(env.get_state()), orc.records), "records after the per-step launches"
+    d_rew = env.alloc((T_fused, n, A), np.float64)
+    d_t = env.alloc((T_fused, n, A), np.uint8)
+    d_u = env.alloc((T_fused, n, A), np.uint8)
+    env.rollout(T_fused, seed, 1000, None, d_rew, d_t, d_u)
+    env.sync()
+    oo, ro, to, uo = orc.rollout(T_fused, seed, 1000)
+    assert np.array_equal(strip(env.get_state()), orc.records), "records after the fused rollout"
+    assert np.array_equal(bits(d_rew.to_host()[-1]), bits(ro)), "last rewards of the fused rollout"
+    assert np.array_equal(d_t.to_host()[-1], to) and np.array_equal(d_u.to_host()[-1], uo)
+    assert np.array_equal(bits(env.observe()), bits(oo)), "observation after the fused rollout"
+    st = env.stats()
+    assert st["episodes"] == int(orc.records[:, soa.W_EPISODE].sum()) + int((orc.records[:, soa.W_STATUS] & 1).sum())
+
+
+def test_config3_full_size_mixed_levels_whole_recipe_book():
+    """BASELINE config 3: 65 536 envs, env e -> level e % 3 of (coop_test, coexistence_test, switch_test), recipes
+    R[e % 8], R[(e + 1) % 8]; short horizon so that auto-resets happen inside the window."""
+    n = 65536
+    rid = np.array([[e % 8, (e + 1) % 8] for e in range(n)])
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    env = CookingVecEnv(n, ["coop_test", "coexistence_test", "switch_test"], "example", 2, 12, rid, action_scheme="scheme3",
+                        num_layouts=256, auto_reset=True)
+    assert n * 2 * env.F * 8 > (128 << 20), "this size must take the plain-store branch of launch_step"
+    _full_size_case(env, steps=16, T_fused=40, seed=31)
+    env.close()
+
+
+def test_config5_full_size_four_agents_16x16():
+    """BASELINE config 5: 65 536 envs x 4 competing agents on large_16x16 (F = 840, 26.9 KB of observation per env-step)."""
+    n = 65536
+    env = make(n, "large_16x16", "large_16x16", 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"],
+               max_steps=6, num_layouts=256)
+    assert env.F == 840
+    _full_size_case(env, steps=8, T_fused=16, seed=32)
+    env.close()
+
+
+def test_config4_one_ranks_shard():
+    """BASELINE config 4, the shard of rank 3 of 8: 32 768 envs with global ids from 98 304 (layout draws and the
+    on-device action stream are keyed by the global id)."""
+    n, base = 32768, 98304
+    env = make(n, "coop_test", "example", 2, ["TomatoLettuceSalad", "CarrotBanana"], max_steps=14, num_layouts=256,
+               env_id_base=base)
+    assert n * 2 * env.F * 8 > (128 << 20)
+    _full_size_case(env, steps=16, T_fused=48, seed=33)
+    env.close()
+
+
+def test_stats_reduction_order_and_size():
+    """The two-stage statistics reduction (64 workgroups of chains + one tree) against a numpy model of its fixed
+    summation order, bit for bit, at 65 536 envs: chain c adds envs c, c+256, ... in order, then a binary tree."""
+    n, T = 65536, 45
+    env = make(n, "coop_test", "example", 2, ["TomatoLettuceSalad", "CarrotBanana"], max_steps=20, num_layouts=64)
+    env.reset(return_obs=False)
+    d_rew = env.alloc((T, n, 2), np.float64)
+    d_t = env.alloc((T, n, 2), np.uint8)
+    d_u = env.alloc((T, n, 2), np.uint8)
+    env.rollout(T, 8, 0, None, d_rew, d_t, d_u)
+    env.sync()
+    rew, done = d_rew.to_host(), (d_t.to_host()[:, :, 0] | d_u.to_host()[:, :, 0]).astype(bool)
+    # per-env sums of finished-episode returns, accumulated the way the kernel does (running return += reward per step)
+    cur = np.zeros((n, 2))
+    fin = np.zeros((n, 2))
+    was_done = np.zeros(n, bool)
+    episodes = 0
+    for t in range(T):
+        stepped = ~was_done
+        cur[stepped] += rew[t][stepped]
+        ended = stepped & done[t]
+        fin[ended] += cur[ended]
+        cur[ended] = 0
+        episodes += int(ended.sum())
+        was_done = ended                                  # the next launch is the reset pass of an ended env
+    chains = np.zeros((256, 2))
+    for j in range(n // 256):
+        chains += fin[j * 256:(j + 1) * 256]
+    level = chains
+    while level.shape[0] > 1:
+        half = level.shape[0] // 2
+        level = level[:half] + level[half:]
+    st = env.stats()
+    assert st["episodes"] == episodes
+    assert np.array_equal(bits(np.array(st["return_sum"][:2])), bits(level[0]))
+    env.close()

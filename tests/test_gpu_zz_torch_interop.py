@@ -1,11 +1,19 @@
 """GPU + PyTorch in one process: device-pointer steps on torch tensors, ordered on torch's stream.
 
 PyTorch's ROCm wheels bundle their own libamdhip64.so.7; the step library links the system one under the same SONAME.
-Whichever is loaded first serves both, and only the order "torch first" works.  On its own this file imports torch
-first; inside a full `pytest tests -m gpu` run the step library is already loaded when this file's turn comes, and
-importing torch then would abort the process at exit, so the test skips itself there."""
+Whichever is loaded first serves both, and only the order "torch first" works.  Inside a full `pytest tests -m gpu` run
+the step library is already loaded when this file's turn comes (importing torch then would abort the process at exit),
+so the test body always runs in a FRESH child interpreter that imports torch first; the parent asserts on its exit code.
+The only skip left is "torch is not installed"."""
+import importlib.util
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
+
+CHILD_FLAG = "CZ_TORCH_INTEROP_CHILD"
 
 pytestmark = pytest.mark.gpu
 
@@ -17,18 +25,18 @@ def bits(a):
 def test_torch_tensors_on_the_callers_stream():
     """Device-pointer steps driven from PyTorch: tensors as buffers, the env ordered on torch's current stream
     (cz_set_stream), no host synchronisation between the producer of the actions, the step and the consumer."""
-    import sys
-    from cooking_zoo_amd import _native
-    if _native._lib is not None and "torch" not in sys.modules:
-        # importing torch now would put its bundled ROCm libraries next to the system ones already in use: that works
-        # while the process lives but aborts in a destructor at exit (seen: "double free or corruption", rc 134)
-        pytest.skip("the step library is already loaded and torch is not: run this file on its own "
-                    "(python -m pytest tests/test_gpu_zz_torch_interop.py -m gpu)")
-    torch = pytest.importorskip("torch")
-    try:
-        torch.cuda.init()                # works if torch's libraries were loaded before the step library (same SONAMEs)
-    except Exception as exc:
-        pytest.skip(f"torch cannot start the HIP runtime in this process ({exc})")
+    if importlib.util.find_spec("torch") is None:
+        pytest.skip("torch is not installed")
+    if not os.environ.get(CHILD_FLAG):
+        env = dict(os.environ)
+        env[CHILD_FLAG] = "1"
+        p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, f"child pytest failed (rc {p.returncode}):\n{p.stdout[-4000:]}\n{p.stderr[-2000:]}"
+        assert "1 passed" in p.stdout, p.stdout[-2000:]
+        return
+    import torch                                  # first: its bundled HIP runtime then serves the step library too
+    torch.cuda.init()
     from cooking_zoo_amd.vec_env import CookingVecEnv
     n, A, T = 512, 2, 40
     kw = dict(action_scheme="scheme3", num_layouts=8, auto_reset=True)
