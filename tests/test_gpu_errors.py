@@ -77,3 +77,36 @@ def test_bad_descriptor_and_ids_are_rejected():
     with pytest.raises(ValueError, match="scheme2"):
         CookingVecEnv(4, "coop_test", "example", 2, 10, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme2")
     env.close()
+
+
+def test_shrinking_the_layout_pool_under_resident_envs_is_refused():
+    """cz_load_layouts with fewer layouts than the resident records refer to must not leave the kernels indexing past the
+    new tables: it is refused until the envs have been reset / set into the new range."""
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    env = CookingVecEnv(64, "coop_test", "example", 2, 10, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3",
+                        num_layouts=8)
+    env.reset(return_obs=False)                       # the envs now sit on layouts 0..7 with the pool slice (0, 8)
+    keep = list(env.layouts)
+    with pytest.raises(_native.NativeError, match="resident env record"):
+        env.set_layouts(keep[:3])
+    env.layouts, env.pool_slices = keep, [(0, 8)]     # (the failed call left the device tables untouched)
+    acts = np.zeros((64, 2), np.int32)
+    env.step(acts)                                    # still steps on the old pool
+    # move every env into the new range first, then the smaller pool is accepted
+    recs = env.get_state()
+    from cooking_zoo_amd import soa
+    recs[:, soa.W_LAYOUT] %= 3
+    recs[:, soa.W_POOL] = 0 | (3 << 16)
+    env.set_state(recs)
+    env.set_layouts(keep[:3])
+    env.step(acts)
+    # host actions outside the scheme's range are refused (negative = despawned is fine)
+    with pytest.raises(ValueError, match="actions must be in"):
+        env.step(np.full((64, 2), 5, np.int32))
+    L, h = _native.lib(), env._h
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    bad = np.full((64, 2), 7, np.int32)
+    rew = np.zeros((64, 2)); te = np.zeros((64, 2), np.uint8); tr = np.zeros((64, 2), np.uint8)
+    assert L.cz_step(h, p(bad), None, p(rew), p(te), p(tr)) != 0 and b"outside [0, 5)" in L.cz_last_error(h)
+    env.step(np.full((64, 2), -1, np.int32))
+    env.close()

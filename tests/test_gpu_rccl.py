@@ -18,3 +18,43 @@ def test_stats_allgather_single_rank():
     assert czd.reduce_stats(gathered)["env_steps"] == local["env_steps"] > 0
     assert local["episodes"] >= 256 * 2
     env.close()
+
+
+def test_comm_barrier_and_runtime_paths_single_rank():
+    import ctypes as C
+    from cooking_zoo_amd import _native, distributed as czd
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    import tempfile
+    env = CookingVecEnv(64, "coop_test", "example", 2, 20, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3",
+                        num_layouts=4, auto_reset=True)
+    env.reset(return_obs=False)
+    L = _native.lib()
+    assert L.cz_comm_barrier(env._h) != 0 and b"not initialised" in L.cz_last_error(env._h)
+    rv = czd.FileRendezvous(tempfile.mkdtemp(prefix="cz_t_"), 0, 1, timeout=30.0)
+    ok, msg = czd.comm_init_with_deadline(env, 1, 0, rv, 120.0)
+    assert ok, msg
+    env.rollout(30, 5)
+    _native.check(env._h, L.cz_comm_barrier(env._h))
+    assert czd.allgather_stats_rccl(env, 1) == [env.stats()]
+    rccl, hip = C.create_string_buffer(512), C.create_string_buffer(512)
+    L.cz_runtime_paths(rccl, hip, 512)
+    assert b"librccl" in rccl.value and b"libamdhip64" in hip.value
+    rv.close()
+    env.close()
+
+
+def test_bench_single_gpu_goes_through_the_multi_rank_code():
+    """`python bench.py --gpus 1` at the driver's K = 20: no torch, the RCCL communicator (1 rank) serves the barrier and
+    the statistics all-gather, and every timed launch is a graph replay."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--repeats", "7",
+                        "--envs", "1024", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["repeats"] == 7
+    assert d["episode_stats_allgather"]["cz_stats_allgather"].startswith("ok, identical")
+    assert d["runtime"]["torch_imported"] is False and "/opt/rocm" in d["runtime"]["hip"]
+    assert "140 were replayed from HIP graphs of 20 launches and 0 launched directly" in d["config"]["api"]
+    assert d["value"] > 1e6 and d["value_min"] <= d["value"] <= d["value_max"]
+    assert 0 < d["roofline"]["frac"] < 1
