@@ -158,6 +158,7 @@ struct cz_handle_s {
     int n_ranks = 1, rank = 0;
     int wt_override = -1;          // CZ_WT experiment switch, read once
     bool graphs_enabled = true;    // CZ_GRAPHS=0: cz_step_device_ring launches everything directly
+    int32_t ring_prefix = 0;       // CZ_RING_PREFIX: steps of a cz_step_device_ring call launched directly in front of its first graph
     size_t zero_copy_bytes = (size_t)256 << 10;   // cz_step: batches whose buffers fit use the pinned device-mapped block (CZ_ZERO_COPY_BYTES)
     cz_stats *d_gather = nullptr;
     std::string err;
@@ -250,6 +251,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     P.stop = -1;
     if (const char *s = getenv("CZ_WT")) h->wt_override = atoi(s);
     if (const char *s = getenv("CZ_GRAPHS")) h->graphs_enabled = atoi(s) != 0;
+    if (const char *s = getenv("CZ_RING_PREFIX")) h->ring_prefix = atoi(s) < 0 ? 0 : (atoi(s) > 16 ? 16 : atoi(s));
     if (const char *s = getenv("CZ_ZERO_COPY_BYTES")) h->zero_copy_bytes = (size_t)atoll(s);
     if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // honoured by the diagnostic build only
     h->kl = (P.D <= 64 && C <= 64) ? launchers_small() : launchers_large();
@@ -678,12 +680,21 @@ static int ring_walk(cz_handle h, int32_t K, const int32_t *d_ring, int64_t stri
         int32_t run = K - k;
         if (run > period - slot) run = period - slot;
         if (run > RING_MAX_GRAPH) run = RING_MAX_GRAPH;
-        if (graphs && run >= RING_MIN_GRAPH) {
+        if (graphs && run >= RING_MIN_GRAPH + h->ring_prefix) {
+            // Replaying a graph costs the host ~10-16 us before its first kernel starts; a directly launched kernel starts
+            // after ~3-5 us.  So the first `ring_prefix` steps of a piece go out as plain launches and keep the GPU busy
+            // while the host submits the graph of the rest behind them.
+            const int32_t pre = k == 0 ? h->ring_prefix : 0;
             hipGraphExec_t ge = nullptr;
-            if (ring_graph(h, P, d_ring, stride, slot, run, ge)) return 1;
+            if (ring_graph(h, P, d_ring, stride, slot + pre, run - pre, ge)) return 1;
             if (launch) {
+                for (int32_t j = 0; j < pre; ++j) {
+                    P.actions = d_ring + (int64_t)(slot + j) * stride;
+                    if (launch_step(h, P)) return 1;
+                }
                 HIPCHK(h, hipGraphLaunch(ge, h->stream));
-                h->n_graph_kernels += run;
+                h->n_graph_kernels += run - pre;
+                h->n_direct_kernels += pre;
             }
         } else if (launch) {
             for (int32_t j = 0; j < run; ++j) {

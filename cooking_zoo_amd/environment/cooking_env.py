@@ -13,8 +13,9 @@ Same constructor kwargs, method names, dict keys and return shapes as the refere
 Agent despawn / respawn (rates > 0) is supported: the random bookkeeping stays on the host (same global RNG streams as
 the reference), the device step is told who acts.
 
-What is deliberately not offered ("out of scope" / "next"): the "symbolic" and "full" observation modes,
-pygame rendering and scheme2 (which raises AttributeError in the reference itself).
+`obs_spaces` entries other than "feature_vector" are served on the host from the env record: "symbolic" rebuilds the
+reference's object view (cooking_world/symbolic.py), "full" is the reference's numeric dict (a constant zero tensor
+upstream).  Deliberately not offered: pygame rendering and scheme2 (which raises AttributeError in the reference itself).
 For many envs at once use cooking_zoo_amd.vec_env.CookingVecEnv -- this facade is the num_envs = 1 case of it.
 """
 from __future__ import annotations
@@ -25,6 +26,7 @@ import numpy as np
 
 from cooking_zoo_amd import soa, spaces
 from cooking_zoo_amd.cooking_book import recipe_drawer
+from cooking_zoo_amd.cooking_world import symbolic
 from cooking_zoo_amd.cooking_world.actions import ACTION_SCHEMES
 from cooking_zoo_amd.cooking_world.engine import load_level as _ll
 from cooking_zoo_amd.vec_env import CookingVecEnv
@@ -66,9 +68,8 @@ class CookingEnvironment:
         obs_spaces = obs_spaces or ["feature_vector"]
         allowed = ["symbolic", "full", "feature_vector"]
         assert len(set(obs_spaces + allowed)) == 3, f"Selected invalid obs spaces. Allowed {allowed}"
-        if any(o != "feature_vector" for o in obs_spaces[:num_agents]):
-            raise NotImplementedError("only the 'feature_vector' observation is produced on the device "
-                                      "('symbolic' deep-copies Python objects, 'full' is constant zeros upstream)")
+        # one entry per agent (cooking_env.py:272); agents past the end of the list get the feature vector
+        self._obs_kind = [obs_spaces[i] if i < len(obs_spaces) else "feature_vector" for i in range(num_agents)]
         if action_scheme == "scheme2":
             raise AttributeError("'CookingWorld' object has no attribute 'perform_agent_action' (scheme2 is unusable in "
                                  "the reference: action_scheme2.py:15)")
@@ -118,7 +119,15 @@ class CookingEnvironment:
         F = self._vec.F
         self.feature_vector_representation_length = F
         self.feature_obs_space = spaces.Box(low=-1, high=1, shape=(F,))
-        self.observation_spaces = {a: self.feature_obs_space for a in self.possible_agents}
+        dims = self._vec.dims
+        self.graph_representation_length = symbolic.GRAPH_REPRESENTATION_LENGTH                  # cooking_env.py:110
+        numeric_obs_space = {"feature_vector": spaces.Box(low=0, high=10, shape=(dims.W, dims.H, self.graph_representation_length),
+                                                          dtype=np.int32),
+                             "agent_location": spaces.Box(low=0, high=max(dims.W, dims.H), shape=(2,)),
+                             "goal_vector": spaces.MultiBinary(self.num_goals)}
+        by_kind = {"full": numeric_obs_space, "feature_vector": self.feature_obs_space, "symbolic": {}}   # cooking_env.py:126-128
+        self.observation_spaces = {a: by_kind[k] for a, k in zip(self.possible_agents, self._obs_kind)}
+        self.current_tensor_observation = np.zeros((dims.W, dims.H, self.graph_representation_length))   # never written upstream
         self.action_spaces = {a: spaces.Discrete(len(self.action_scheme_class.ACTIONS)) for a in self.possible_agents}
         self.rewards = {a: 0 for a in self.agents}
         self.terminations = {a: False for a in self.agents}
@@ -175,7 +184,7 @@ class CookingEnvironment:
         self.truncations = {a: False for a in self.agents}
         self.infos = {a: {} for a in self.agents}
         self._needs_reset = False
-        return {a: obs[0, i].copy() for i, a in enumerate(self.agents)}, dict(self.infos)
+        return self._observations(obs, range(n)), dict(self.infos)
 
     def step(self, actions):
         """One accumulated_step (cooking_env.py:243-269) + observe for every agent (cooking_env.py:271-288).
@@ -207,10 +216,9 @@ class CookingEnvironment:
         done = bool(term[0, 0])
         info = {"t": self.t, "termination_info": self.termination_info}
         self.rewards, self.terminations, self.truncations, self.infos = {}, {}, {}, {}
-        observations = {}
+        observations = self._observations(obs, relevant)
         for k, i in enumerate(relevant):
             a = self.possible_agents[i]
-            observations[a] = obs[0, i].copy()
             # the reference scatters the per-RECIPE rewards by position in the relevant list (cooking_env.py:255-261):
             # with everybody present that is the agent's own recipe, otherwise the k-th one
             self.rewards[a] = np.float64(rew[0, k])
@@ -277,7 +285,33 @@ class CookingEnvironment:
                 raise ValueError(f"Can't find valid position in {time_out} steps")
 
     def observe(self, agent):
-        return self._vec.observe()[0, self.possible_agents.index(agent)].copy()
+        """cooking_env.py:271-288: the observation of one agent in the mode its `obs_spaces` entry names."""
+        i = self.possible_agents.index(agent)
+        obs = self._vec.observe() if self._obs_kind[i] == "feature_vector" else None
+        return self._observations(obs, [i])[agent]
+
+    def _observations(self, obs, agent_indices):
+        """{player_i: observation} for the given agents.  "feature_vector": the device-encoded float64 vector;
+        "symbolic": a fresh object view of the world rebuilt from the env record (cooking_world/symbolic.py; the
+        reference deep-copies its object graph, so every agent gets objects of its own); "full": the reference's numeric
+        dict, whose tensor is constant zeros upstream (cooking_env.py:149,273-278)."""
+        out = {}
+        record = None
+        for i in agent_indices:
+            kind, a = self._obs_kind[i], self.possible_agents[i]
+            if kind == "feature_vector":
+                out[a] = obs[0, i].copy()
+                continue
+            if record is None:
+                record = self._vec.get_state()[0]
+            if kind == "symbolic":
+                out[a] = symbolic.materialize(self._vec.dims, self._cached_layout, record)
+            else:
+                x, y, _, _ = soa.unpack_agent(record[soa.AGENT_WORD0 + i])
+                out[a] = {"feature_vector": self.current_tensor_observation,
+                          "agent_location": np.asarray((x, y), np.int32),
+                          "goal_vector": self.recipe_graphs[i].goals_completed(self.num_goals)}
+        return out
 
     def _refresh_marks(self):
         self._set_marks(int(self._vec.get_state()[0, soa.W_MARKS]))

@@ -3,7 +3,7 @@ duck-typed stand-ins with the same attributes (shape, dtype, low, high, n, sampl
 import numpy as np
 
 try:                                            # pragma: no cover - depends on the environment
-    from gymnasium.spaces import Box, Discrete  # type: ignore
+    from gymnasium.spaces import Box, Discrete, MultiBinary  # type: ignore
     HAVE_GYMNASIUM = True
 except Exception:                               # gymnasium is not installed in the build container
     HAVE_GYMNASIUM = False
@@ -39,3 +39,19 @@ except Exception:                               # gymnasium is not installed in 
 
         def __repr__(self):
             return f"Discrete({self.n})"
+
+    class MultiBinary:
+        def __init__(self, n):
+            self.n = int(n)
+            self.shape = (self.n,)
+            self.dtype = np.dtype(np.int8)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and bool(np.all((x == 0) | (x == 1)))
+
+        def sample(self):
+            return np.random.randint(0, 2, size=self.shape).astype(self.dtype)
+
+        def __repr__(self):
+            return f"MultiBinary({self.n})"

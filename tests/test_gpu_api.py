@@ -72,8 +72,8 @@ def test_full_reset_false_reuses_layout_and_gym_wrappers():
 def test_unsupported_modes_fail_loudly():
     from cooking_zoo_amd.environment.cooking_env import parallel_env
     kw = dict(level="coop_test", meta_file="example", num_agents=1, max_steps=10, recipes=["TomatoSalad"])
-    with pytest.raises(NotImplementedError):
-        parallel_env(obs_spaces=["symbolic"], action_scheme="scheme3", **kw)
+    with pytest.raises(AssertionError):
+        parallel_env(obs_spaces=["pixels"], action_scheme="scheme3", **kw)         # cooking_env.py:85-86
     with pytest.raises(AttributeError):
         parallel_env(action_scheme="scheme2", **kw)
     from cooking_zoo_amd.environment.cooking_env import env as aec_env

@@ -5,7 +5,7 @@ Whichever is loaded first serves both, and only the order "torch first" works.  
 the step library is already loaded when this file's turn comes (importing torch then would abort the process at exit),
 so the test body always runs in a FRESH child interpreter that imports torch first; the parent asserts on its exit code.
 The only skip left is "torch is not installed"."""
-import importlib.util
+import importlib.machinery
 import os
 import subprocess
 import sys
@@ -25,7 +25,8 @@ def bits(a):
 def test_torch_tensors_on_the_callers_stream():
     """Device-pointer steps driven from PyTorch: tensors as buffers, the env ordered on torch's current stream
     (cz_set_stream), no host synchronisation between the producer of the actions, the step and the consumer."""
-    if importlib.util.find_spec("torch") is None:
+    # (PathFinder: sys.meta_path may hold cooking_zoo_amd's guard against importing torch AFTER the step library)
+    if "torch" not in sys.modules and importlib.machinery.PathFinder.find_spec("torch") is None:
         pytest.skip("torch is not installed")
     if not os.environ.get(CHILD_FLAG):
         env = dict(os.environ)

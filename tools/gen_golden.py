@@ -719,6 +719,7 @@ def main():
     sets["api_traces"] = lambda: api_traces(args.out)
     sets["layouts_ref"] = lambda: layout_draws(args.out)
     sets["aec_traces"] = lambda: aec_traces(args.out)
+    sets["symbolic_traces"] = lambda: symbolic_traces(args.out)
     for name, fn in sets.items():
         if args.only and args.only != name:
             continue
@@ -804,6 +805,79 @@ def api_traces(out_dir):
     with open(path, "w") as f:
         json.dump(out, f)
     print(f"[golden] api_traces: {len(out)} cases, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def symbolic_traces(out_dir):
+    """obs_spaces "symbolic" / "full" through the reference's parallel_env (cooking_env.py:271-288): per step the action
+    dict and the object view of the world as plain data (cooking_zoo_amd.cooking_world.symbolic.physical_view: per
+    class, in dict-key and list order, the `physical_state` attributes with object references as [class, index]).  In
+    the first case player_0 is driven by the reference's own heuristic CookingAgent fed with that symbolic observation
+    (its intended consumer), so the trace contains chopping, plating and a delivery."""
+    import gzip
+    from cooking_zoo_amd.cooking_world.symbolic import physical_view
+    crowd = os.path.join(REPO, "cooking_zoo_amd", "utils", "level", "crowded_6x5.json")
+    metac = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", "crowded_6x5.json")
+    cases = [
+        dict(name="coop_heuristic", seed=31, steps=150, policy_seed=1, heuristic="TomatoLettuceSalad",
+             kwargs=dict(level="coop_test", meta_file="example", num_agents=2, max_steps=150,
+                         recipes=["TomatoLettuceSalad", "CarrotBanana"], obs_spaces=["symbolic", "feature_vector"],
+                         end_condition_all_dishes=True, action_scheme="scheme3")),
+        dict(name="switch_scheme1", seed=32, steps=80, policy_seed=2, heuristic=None,
+             kwargs=dict(level="switch_test", meta_file="example", num_agents=2, max_steps=80,
+                         recipes=["MashedCarrotBanana", "TomatoSalad"], obs_spaces=["symbolic", "symbolic"],
+                         action_scheme="scheme1")),
+        dict(name="crowded_4agents", seed=33, steps=70, policy_seed=3, heuristic=None,
+             kwargs=dict(level=crowd, meta_file=metac, num_agents=4, max_steps=70,
+                         recipes=["TomatoSalad", "TomatoLettuceSalad", "no_recipe", "MashedCarrotBanana"],
+                         obs_spaces=["symbolic", "feature_vector", "symbolic", "full"], action_scheme="scheme3")),
+        dict(name="coop_full", seed=34, steps=25, policy_seed=4, heuristic=None,
+             kwargs=dict(level="coop_test", meta_file="example", num_agents=1, max_steps=25, recipes=["TomatoLettuceSalad"],
+                         obs_spaces=["full"], action_scheme="scheme3")),
+    ]
+
+    def plain(o):
+        """one agent's observation as JSON-able data"""
+        if isinstance(o, np.ndarray):
+            return {"kind": "feature_vector", "sha256": hashlib.sha256(np.ascontiguousarray(o, dtype=np.float64).tobytes()).hexdigest()}
+        if isinstance(o, dict) and "agent_location" in o:
+            return {"kind": "full", "tensor_shape": list(o["feature_vector"].shape), "tensor_abs_sum": float(np.abs(o["feature_vector"]).sum()),
+                    "agent_location": [int(v) for v in o["agent_location"]], "agent_location_dtype": str(o["agent_location"].dtype),
+                    "goal_vector": [int(v) for v in o["goal_vector"]]}
+        return {"kind": "symbolic", "view": physical_view(o)}
+
+    out = []
+    for case in cases:
+        random.seed(case["seed"])
+        np.random.seed(case["seed"])
+        env = parallel_env(**case["kwargs"])
+        obs, _ = env.reset()
+        prng = np.random.default_rng(case["policy_seed"])
+        n_act = int(env.action_space("player_0").n)
+        bot = CookingAgent(case["heuristic"], "agent-1") if case["heuristic"] else None
+        kw = dict(case["kwargs"])
+        for key in ("level", "meta_file"):
+            if os.path.isabs(kw[key]):
+                kw[key] = os.path.splitext(os.path.basename(kw[key]))[0]
+        rec = {"name": case["name"], "seed": case["seed"], "kwargs": kw, "reset_obs": {k: plain(v) for k, v in obs.items()}, "steps": []}
+        delivered = False
+        for t in range(case["steps"]):
+            if not env.agents:
+                break
+            ad = {a: int(prng.integers(n_act)) for a in env.agents}
+            if bot is not None and "player_0" in ad and prng.random() > 0.05:
+                ad["player_0"] = int(bot.step(obs["player_0"]))
+            obs, r, te, tr, inf = env.step(ad)
+            delivered |= any(v > 1 for v in r.values())
+            rec["steps"].append({"action_dict": ad, "obs": {k: plain(v) for k, v in obs.items()},
+                                 "rewards": {k: float(v) for k, v in r.items()}, "agents_after": list(env.agents)})
+        if bot is not None:
+            assert delivered, "the heuristic agent was expected to deliver its dish inside the trace"
+        out.append(rec)
+        print(f"[golden] symbolic_traces/{case['name']}: {len(rec['steps'])} steps" + (" (dish delivered)" if delivered else ""))
+    path = os.path.join(out_dir, "symbolic_traces.json.gz")
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(json.dumps(out, sort_keys=False).encode())
+    print(f"[golden] symbolic_traces: {len(out)} cases, {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 def aec_traces(out_dir):
