@@ -366,6 +366,10 @@ def worker(args):
         rdzv.close()
     except Exception:
         pass
+    # RCCL prints a version banner through C stdio, which reaches fd 1 when the process exits: after the JSON line nothing
+    # else may appear on stdout, so fd 1 is pointed at /dev/null for whatever the libraries still hold in their buffers
+    sys.stdout.flush()
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if rc != 0:
         sys.stdout.flush()
         os._exit(rc)                             # a communicator stuck in bring-up cannot be torn down: leave, visibly failed

@@ -28,23 +28,38 @@ class RecipeNode:
         return not bool(self.contains)
 
 
-def _condition_code(conditions):
-    """(attr, value) pairs -> one device condition code.  The device evaluates at most one
-    state predicate per node (every recipe the reference ships has zero or one)."""
+_BLENDER_FOOD = ("Carrot", "Banana")                     # the only classes with a blend_state (abstract_classes.py:257-264)
+
+
+def _condition_code(conditions, class_name=""):
+    """(attr, value) pairs -> one device condition code (include/cookingzoo.h, cz_load_recipes).
+
+    An object's recipe-visible state is two bits (chopped, mashed), so ANY number of conditions on chop_state /
+    blend_state (recipe.py:96-98 loops over all of them) is exactly a set of accepted states
+    s = chopped | mashed << 1.  One condition keeps the legacy codes 1..4; several become 0x10 | accept mask.
+    Deviations: a blend_state condition on a class without that attribute (the reference raises AttributeError as soon
+    as such an object exists) and BlenderFoodStates.IN_PROGRESS (never observable between steps) match nothing."""
     if not conditions:
         return soa.COND_NONE
-    if len(conditions) > 1:
-        raise ValueError("at most one (attribute, value) condition per recipe node is supported")
-    attr, value = conditions[0]
-    value = getattr(value, "value", value)
-    table = {("chop_state", ChopFoodStates.CHOPPED.value): soa.COND_CHOPPED,
-             ("chop_state", ChopFoodStates.FRESH.value): soa.COND_NOT_CHOPPED,
-             ("blend_state", BlenderFoodStates.MASHED.value): soa.COND_MASHED,
-             ("blend_state", BlenderFoodStates.FRESH.value): soa.COND_NOT_MASHED}
-    try:
-        return table[(attr, value)]
-    except KeyError:
-        raise ValueError(f"unsupported recipe condition {conditions[0]!r}") from None
+    accept = 0xF
+    single = None
+    for attr, value in conditions:
+        value = getattr(value, "value", value)
+        if attr == "chop_state" and value == ChopFoodStates.CHOPPED.value:
+            accept &= 0xA; single = soa.COND_CHOPPED
+        elif attr == "chop_state" and value == ChopFoodStates.FRESH.value:
+            accept &= 0x5; single = soa.COND_NOT_CHOPPED
+        elif attr == "blend_state" and value == BlenderFoodStates.MASHED.value:
+            accept &= 0xC if class_name in _BLENDER_FOOD else 0; single = soa.COND_MASHED
+        elif attr == "blend_state" and value == BlenderFoodStates.FRESH.value:
+            accept &= 0x3 if class_name in _BLENDER_FOOD else 0; single = soa.COND_NOT_MASHED
+        elif attr == "blend_state" and value == BlenderFoodStates.IN_PROGRESS.value:
+            accept = 0; single = None
+        else:
+            raise ValueError(f"unsupported recipe condition {(attr, value)!r}")
+    if len(conditions) == 1 and single is not None:
+        return single
+    return 0x10 | accept
 
 
 class Recipe:
@@ -93,6 +108,6 @@ class Recipe:
             for c in n.contains:
                 child_mask |= 1 << index[id(c)]
             counts = 1 if last_with_id[n.id_num] == j else 0
-            out[1 + j] = (soa.class_node_id(n.name) | (_condition_code(n.conditions) << 8) | (child_mask << 16)
+            out[1 + j] = (soa.class_node_id(n.name) | (_condition_code(n.conditions, n.name) << 8) | (child_mask << 16)
                           | (counts << 24))
         return out

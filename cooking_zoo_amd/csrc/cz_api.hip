@@ -347,33 +347,37 @@ extern "C" int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n) {
     if (h->d_recipes) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->d_recipes)); h->d_recipes = nullptr; h->P.recipes = nullptr; }
     size_t bytes = (size_t)n * (1 + MAX_NODES) * 4;
     HIPCHK(h, hipMalloc(&h->d_recipes, bytes));
-    // device copy: word 0 = node count | (mask of dynamic classes the nodes name) << 8; node words are re-encoded as
-    // compare masks (layout documented at Ops::recipe_marks in cz_device.h)
+    // device copy: word 0 = node count; node words are re-encoded for the kernels (layout documented at
+    // Ops::recipe_marks in cz_device.h): conditions become an accept mask over the state index chopped | mashed << 1
     std::vector<uint32_t> dev(table, table + (size_t)n * (1 + MAX_NODES));
     for (int i = 0; i < n; ++i) {
-        uint32_t *row = dev.data() + (size_t)i * (1 + MAX_NODES), mask = 0;
+        uint32_t *row = dev.data() + (size_t)i * (1 + MAX_NODES);
         const uint32_t nn = row[0];
         for (uint32_t j = 0; j < MAX_NODES; ++j) {
             const uint32_t hw = row[1 + j];
             const uint32_t cls = hw & 0xFF, cond = (hw >> 8) & 0xFF, children = (hw >> 16) & 0xFF, counts = (hw >> 24) & 1;
-            uint32_t w = (children << 2) | (counts << 10);
+            uint32_t w = children | (counts << 8);
             if (j >= nn) { row[1 + j] = 0; continue; }
             if (cls < 16) {
-                w |= 0x800u | ((cls & 7u) << 12);
-                if (cls > BLENDER) w |= 0x06000003u;                          // unknown static class: matches nothing
+                w |= 0x200u | ((cls <= BLENDER ? cls : 7u) << 10);                  // unknown static class: matches nothing
             } else if (cls < 32) {
-                mask |= 1u << (cls - 16);
-                w |= ((cls - 16) << 16) | D_ALIVE;
-                if (cond == COND_CHOPPED) w |= 1u | D_CHOPPED;
-                else if (cond == COND_MASHED) w |= 2u | D_MASHED;
-                else if (cond == COND_NOT_CHOPPED) w |= 1u;
-                else if (cond == COND_NOT_MASHED) w |= 2u;
-            } else {
-                w |= (0xFFu << 16);                                           // class with no objects (e.g. "Agent"): never alive
+                // states: 0 fresh, 1 chopped, 2 mashed, 3 both.  Only Carrot / Banana have a blend_state (the reference
+                // raises AttributeError when a blend condition meets another class; here such a node matches nothing)
+                const bool blender_food = (cls - 16) == CARROT || (cls - 16) == BANANA;
+                uint32_t acc;
+                if (cond & 0x10u) acc = cond & 0xFu;                               // explicit accept mask (several conditions)
+                else if (cond == COND_NONE) acc = 0xFu;
+                else if (cond == COND_CHOPPED) acc = 0xAu;
+                else if (cond == COND_NOT_CHOPPED) acc = 0x5u;
+                else if (cond == COND_MASHED) acc = blender_food ? 0xCu : 0u;
+                else if (cond == COND_NOT_MASHED) acc = blender_food ? 0x3u : 0u;
+                else return fail(h, "cz_load_recipes: recipe %d node %u: unknown condition code %u", i, j, cond);
+                w |= 0x2000u | ((cls - 16) << 16) | (acc << 24);
             }
+            // (any other class id, e.g. 255 for a name without objects such as "Agent": neither flag, matches nothing)
             row[1 + j] = w;
         }
-        row[0] = (nn & 0xFFu) | (mask << 8);
+        row[0] = nn & 0xFFu;
     }
     HIPCHK(h, hipMemcpyAsync(h->d_recipes, dev.data(), bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

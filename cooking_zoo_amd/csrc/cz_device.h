@@ -190,7 +190,10 @@ struct Dirty {                     // what this step changed (uniform)
     uint32_t interacted;           // containment / free flags may have changed  -> free-flag normalisation needed
     uint32_t cells;                // some mutable cell bit changed              -> the cell bytes must be written back
     uint32_t moved;                // a held object was carried to another cell  -> objects must be written back
-    uint32_t classes;              // bit c: an object of dynamic class c moved or changed state (recipe filter); ~0 = any
+    uint32_t statechg;             // some object changed its chop / blend state or was created (not a mere move)
+    uint64_t kinds;                // bit 4c + s: an object of dynamic class c in state s = chopped | mashed << 1 moved or
+                                   // changed (both its old and its new state are recorded); ~0 = anything (a plate drags
+                                   // its content along).  Recipe filter, see step_env.
 };
 
 // dx + 1 / dy + 1 of get_target_location (cooking_world.py:172-184), two bits per action code 0..7
@@ -281,11 +284,17 @@ struct Ops {
     // One agent's view while it acts (uniform scalars, written back by the caller)
     struct Me { int x, y, o, h; };
 
-    // record that the object with dyn0 word `w` moved or changed state; a plate drags its content along -> any class
+    // record that the object with dyn0 word `w` moved; a plate drags its content along -> anything
     static __device__ __forceinline__ void touch(Dirty &dt, uint32_t w) {
         const uint32_t cls = (w >> 16) & 0xFFu;
         dt.touched = 1;
-        dt.classes |= (cls == PLATE) ? 0xFFFFFFFFu : (1u << cls);
+        dt.kinds |= (cls == PLATE) ? ~0ull : (1ull << (4u * cls + ((w >> 25) & 3u)));
+    }
+    // ... or changed from `before` to `after` (chopped, mashed, created)
+    static __device__ __forceinline__ void touch_change(Dirty &dt, uint32_t before, uint32_t after) {
+        touch(dt, before);
+        touch(dt, after);
+        dt.statechg = 1;
     }
 
     // cooking_world.py:243-261 attempt_merge (first matching branch only, no fall-through on refusal).
@@ -418,7 +427,7 @@ struct Ops {
                     }
             }
             cell_update(e, cx, c, CELL_READY, 0, dt);
-            touch(dt, fw);
+            touch_change(dt, fw, fw | D_CHOPPED);               // (a Bread clone is a chopped Bread too)
             dt.interacted = 1;
         } else if (ty == BLENDER) {
             if (sv & CELL_READY) cell_update(e, cx, c, 0, CELL_TOGGLE, dt);
@@ -552,7 +561,9 @@ struct Ops {
                 OM mashed = content & oballot(e, [](uint32_t a, uint32_t) { return (a & D_MASHED) != 0; });
                 if (mashed.count() == content.count()) cell_update(e, cx, c, CELL_READY | CELL_TOGGLE, 0, dt);
                 dt.touched = 1;
-                dt.classes |= (1u << CARROT) | (1u << BANANA);          // the only BlenderFood classes
+                dt.statechg = 1;
+                // the only BlenderFood classes; fresh (state 0) items become mashed (state 2)
+                dt.kinds |= (5ull << (4u * CARROT)) | (5ull << (4u * BANANA));
                 dt.interacted = 1;
             }
         }
@@ -632,13 +643,15 @@ struct Ops {
 
     // recipe.py:77-104 update_recipe_state for one recipe graph; returns the marks byte (bit j = node j marked).
     // Device node word (built by cz_load_recipes from the host table):
-    //   bit 0 / 1   the compare mask includes CHOPPED / MASHED        bits 2..9  child mask
-    //   bit 10      counts in the goal sum                            bit 11     static class (bits 12..14 = cell type)
-    //   bits 16..26 the value (word & compare mask) must equal: class<<16 | ALIVE | wanted CHOPPED / MASHED bits
+    //   bits 0..7   child mask                 bit 8       counts in the goal sum
+    //   bit 9       static class, bits 10..12 = cell type (7 = matches nothing)
+    //   bit 13      dynamic class: bits 16..23 = class id (as in dyn0), bits 24..27 = the accept mask over the object's
+    //               state index chopped | mashed << 1 -- every combination of (attr, value) conditions on chop_state /
+    //               blend_state (recipe.py:96-98) is one such mask, so a node may carry any number of conditions
     // A node's matched set is kept as a bit set of CELLS (LDS scratch `locs`), because the only thing a parent asks of
     // a child's matches is location equality (recipe.py:103).  Children always follow their parent in node_list, so
-    // one pass from the last node to the first suffices.  Rolled: this is a cold path (steps that changed an object of
-    // one of the recipe's classes) and must not bloat the hot path's registers.
+    // one pass from the last node to the first suffices.  Rolled: this is a cold path (steps that changed an object the
+    // recipe can see, see step_env) and must not bloat the hot path's registers.
     static __device__ __forceinline__ uint32_t recipe_marks(const E &e, const Ctx &cx, uint32_t rowv, int rbase,
                                                             uint64_t *__restrict__ locs) {
         const int n = (int)(rdl(rowv, rbase) & 0xFFu);
@@ -646,14 +659,15 @@ struct Ops {
 #pragma nounroll
         for (int j = n - 1; j >= 0; --j) {
             const uint32_t w = rdl(rowv, rbase + 1 + j);
-            const uint32_t children = (w >> 2) & 0xFFu;
+            const uint32_t children = w & 0xFFu;
             if ((marks & children) != children) continue;                 // all(contains.marked)
-            const uint32_t cval = w & 0x07FF0000u, cmask = 0x01FF0000u | ((w & 3u) << 25);
+            const uint32_t cval = (w & 0x00FF0000u) | D_ALIVE, acc = (w >> 24) & 0xFu;
+            auto matches = [=](uint32_t a) { return (a & 0x01FF0000u) == cval && ((acc >> ((a >> 25) & 3u)) & 1u) != 0u; };
             CM here = CM::zero();
             bool any;
-            if (children == 0u && !(w & 0x800u)) {
+            if (children == 0u && !(w & 0x200u)) {
                 // leaf of a dynamic class (the common case): no location constraint
-                OM m = oballot(e, [=](uint32_t a, uint32_t) { return (a & cmask) == cval; });
+                OM m = oballot(e, [=](uint32_t a, uint32_t) { return matches(a); });
                 any = m.any();
                 while (j > 0 && m.any()) {                                 // record where the matches are (a handful at most)
                     const int s = m.first();
@@ -676,8 +690,8 @@ struct Ops {
                         allow.w[q] &= ((uint64_t)rfl((uint32_t)(lw >> 32)) << 32) | rfl((uint32_t)lw);
                     }
                 }
-                if (w & 0x800u) {                                         // a static class: candidates are cells
-                    const uint32_t cls = (w >> 12) & 7u;
+                if (w & 0x200u) {                                         // a static class: candidates are cells
+                    const uint32_t cls = (w >> 10) & 7u;
 #pragma unroll
                     for (int k = 0; k < CPL; ++k)
                         here.w[k] = ballot((e.cell[k] & CELL_TYPE) == cls && (cx.lane + 64 * k) < cx.C) & allow.w[k];
@@ -693,7 +707,7 @@ struct Ops {
                             for (int q = 1; q < CPL; ++q)
                                 if ((mycell >> 6) == (uint32_t)q) wsel = allow.w[q];
                         }
-                        m.w[k] = ballot((e.d0[k] & cmask) == cval && ((wsel >> (mycell & 63)) & 1));
+                        m.w[k] = ballot(matches(e.d0[k]) && ((wsel >> (mycell & 63)) & 1));
                     }
                     any = m.any();
                     while (j > 0 && m.any()) {

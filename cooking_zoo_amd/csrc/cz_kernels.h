@@ -280,7 +280,7 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
 }
 
 struct StepOut {
-    double rew[MAX_AGENTS];
+    double myrew;                  // lane a < NA: the reward of agent a (cooking_env.py:255-261); 0.0 on the other lanes
     uint32_t term, trunc;
     bool stepped, finished;        // a world step was executed / it ended the episode
 };
@@ -290,8 +290,7 @@ template <int OPL, int CPL, int NA, int SCHEME>
 __device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t acts,
                                          int64_t env_global, uint32_t &rowv, Lds &lds, uint32_t (&dsc)[OBS_CHUNK], Dirty &dt, StepOut &o) {
     using O = Ops<OPL, CPL, NA, SCHEME>;
-#pragma unroll
-    for (int a = 0; a < MAX_AGENTS; ++a) o.rew[a] = 0.0;
+    o.myrew = 0.0;
     o.term = 0; o.trunc = 0; o.stepped = false; o.finished = false;
     if (e.status & ST_DONE) {
         if (P.auto_reset) {
@@ -303,7 +302,7 @@ __device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, 
             e.t = 0; e.layout = lay; e.status = 0; e.episode = episode; e.recipes = recipes; e.pool = pool;
             e.marks = all_marks(P, e, cx, rowv, lds);
             if (P.obs) load_desc(P, lay, 0, cx.lane, dsc);
-            dt.cells = 1; dt.touched = 1; dt.interacted = 1; dt.classes = 0xFFFFFFFFu;         // everything must be written back
+            dt.cells = 1; dt.touched = 1; dt.interacted = 1;          // everything must be written back
         } else {
             o.term = (e.status & ST_TERM) ? 1u : 0u;
             o.trunc = (e.status & ST_TRUNC) ? 1u : 0u;
@@ -323,36 +322,43 @@ __device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, 
     const bool truncated = (int)e.t >= P.max_steps;                 // compute_truncated :333-350
     const uint32_t before = e.marks;
     uint32_t after = before;
-#pragma unroll
-    for (int a = 0; a < NA; ++a) o.rew[a] = P.reward_idle;
-    if (dt.moved & (uint32_t)P.walk_touches) { dt.touched = 1; dt.classes = 0xFFFFFFFFu; }
+    o.myrew = cx.lane < NA ? P.reward_idle : 0.0;
+    if (dt.moved & (uint32_t)P.walk_touches) { dt.touched = 1; dt.kinds = ~0ull; }
     if (dt.touched) {
+        // Which recipes must be re-evaluated?  Marks are a pure function of object state, and (recipe.py:77-104)
+        //  * an object that matches no node of a recipe (class + state conditions) neither before nor after its change is
+        //    in no node's matched list either way, and nothing else asks where it is: the recipe cannot see it;
+        //  * a mere MOVE leaves every leaf's mark alone (leaves have no location constraint), so it can only matter to a
+        //    node that has children, and such a node is only looked at when all its children are marked: if no node of
+        //    the recipe is in that position now, no mark can change (induction from the leaves up).
+        // Both tests run for all nodes of all recipes at once: lane 9r + 1 + j holds node j of recipe r (rowv).
+        const uint32_t nw = rowv, lane_u = (uint32_t)cx.lane;
+        const uint32_t r_of = (lane_u * 57u) >> 9;                                   // lane / 9
+        const uint32_t seen = (uint32_t)(dt.kinds >> ((nw >> 14) & 0x3Cu)) & ((nw >> 24) & 0xFu);
+        const uint32_t kids = nw & 0xFFu, mb = (before >> (8u * (r_of & 3u))) & 0xFFu;
+        constexpr uint64_t NODE_LANES = 0x1FEull | (0x1FEull << 9) | (0x1FEull << 18) | (0x1FEull << 27);
+        const uint64_t relmask = ballot((nw & 0x2000u) != 0u && seen != 0u) & NODE_LANES;
+        const uint64_t sensmask = ballot(kids != 0u && (mb & kids) == kids) & NODE_LANES;
         after = 0;
 #pragma nounroll
         for (int r = 0; r < P.R; ++r) {
-            const uint32_t mb = (before >> (8 * r)) & 0xFF;
-            // a recipe's marks depend only on objects of its node classes (row word 0 bits 8..: dynamic-class mask)
-            const bool affected = ((rdl(rowv, 9 * r) >> 8) & dt.classes) != 0u;
-            const uint32_t ma = affected ? O::recipe_marks(e, cx, rowv, 9 * r, lds.locs) : mb;
+            const uint32_t mb_r = (before >> (8 * r)) & 0xFF;
+            const bool visible = ((relmask >> (9 * r + 1)) & 0xFFull) != 0ull;
+            const bool sensitive = dt.statechg != 0u || ((sensmask >> (9 * r + 1)) & 0xFFull) != 0ull;
+            const uint32_t ma = (visible && sensitive) ? O::recipe_marks(e, cx, rowv, 9 * r, lds.locs) : mb_r;
             after |= ma << (8 * r);
-            if (ma != mb) {
+            if (ma != mb_r) {
                 // goals_completed sums (recipe.py:36-40): open goal slots before / after
-                uint32_t countmask = 0;
-                const int n = (int)(rdl(rowv, 9 * r) & 0xFFu);
-#pragma unroll
-                for (int j = 0; j < MAX_NODES; ++j)
-                    if (j < n && ((rdl(rowv, 9 * r + 1 + j) >> 10) & 1)) countmask |= 1u << j;
-                const int goals_before = __popc(~mb & countmask), goals_after = __popc(~ma & countmask);
-                const bool completed = ma & 1, completion_before = mb & 1;
+                const uint32_t countmask = (uint32_t)((ballot((nw & 0x100u) != 0u) >> (9 * r + 1)) & 0xFFull);
+                const int goals_before = __popc(~mb_r & countmask), goals_after = __popc(~ma & countmask);
+                const bool completed = ma & 1, completion_before = mb_r & 1;
                 const bool malus = !completed && completion_before, bonus = completed && !completion_before;
                 double x = 0.0;
                 x += (double)(goals_before - goals_after) * P.node_reward;
                 x += (bonus ? 1.0 : 0.0) * P.recipe_reward;
                 x += (malus ? 1.0 : 0.0) * P.recipe_penalty;
                 x += P.time_penalty_step;
-#pragma unroll
-                for (int a = 0; a < NA; ++a)
-                    if (r == a) o.rew[a] = x;
+                if (cx.lane == r && r < NA) o.myrew = x;                   // recipe r is agent r's (cooking_env.py:255-261)
             }
         }
     }
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(const Params P) {
         uint32_t acts;                                             // lane a = action of agent a
         if (!FUSED) acts = (uint32_t)av;
         else acts = action_hash(P.seed, env_global, lane & 3, P.step0 + (uint32_t)t, SCHEME == 3 ? 5u : 8u);
-        Dirty dt{0, 0, 0, 0, 0, 0};
+        Dirty dt{};
         StepOut o;
         step_env<OPL, CPL, NA, SCHEME>(P, e, cx, acts, env_global, rowv, lds, dsc, dt, o);
 #if defined(CZ_ABLATE)
@@ -423,10 +429,7 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(const Params P) {
         cells_dirty |= dt.cells != 0;
         objs_dirty |= (dt.touched | dt.interacted | dt.moved) != 0;
         // ---- running return (lane a = agent a) and, at episode end only, the per-env statistics
-        double myrew = 0.0;
-#pragma unroll
-        for (int a = 0; a < NA; ++a)
-            if (lane == a) myrew = o.rew[a];
+        const double myrew = o.myrew;
         if (o.stepped) ret += myrew;
         if (o.finished) {
             uint32_t *su = P.stat_u + (size_t)env * SU_WORDS;

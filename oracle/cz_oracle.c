@@ -612,8 +612,17 @@ static uint32_t update_recipe_state(const World *w, const Recipe *r)
             }
             /* check_conditions recipe.py:96-104 */
             int ok = 1;
-            if (cond == COND_CHOPPED) ok = chopped; else if (cond == COND_MASHED) ok = mashed;
-            else if (cond == COND_NOT_CHOPPED) ok = !chopped; else if (cond == COND_NOT_MASHED) ok = !mashed;
+            if (cond & 0x10) {
+                /* several (attr, value) conditions, handed over as the set of object states (chopped | mashed << 1)
+                 * that satisfy all of them: recipe.py:96-98 loops over every condition of the node */
+                ok = cls >= 16 && (((cond & 15) >> (chopped | (mashed << 1))) & 1);
+            } else {
+                /* blend_state exists on Carrot / Banana only (abstract_classes.py:257-264); on any other class the
+                 * reference's getattr raises -- documented deviation: such a node matches nothing */
+                int has_blend = cls == 16 + CARROT || cls == 16 + BANANA;
+                if (cond == COND_CHOPPED) ok = chopped; else if (cond == COND_MASHED) ok = has_blend && mashed;
+                else if (cond == COND_NOT_CHOPPED) ok = !chopped; else if (cond == COND_NOT_MASHED) ok = has_blend && !mashed;
+            }
             if (!ok) continue;
             for (int c = 0; c < CZO_MAX_NODES && ok; ++c) {
                 if (!(children & (1 << c))) continue;
