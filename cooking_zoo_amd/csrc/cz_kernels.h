@@ -376,8 +376,26 @@ __device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, 
 
 // ENVS_PER_WG envs per workgroup (one wavefront each, no cross-wave communication).
 // FUSED = false: one step, actions from memory.  FUSED = true: P.T steps, on-device action stream, outputs [t][env].
+// What the very first loads of a wave need travels as leading scalar kernel arguments: the build preloads them into
+// SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, gfx940+), so the record / action / table loads are issued
+// without waiting for an argument fetch; everything else stays in the by-value block `P0`, fetched meanwhile.
+struct Early {
+    uint32_t *state;               // Params::state
+    const int32_t *actions;        // Params::actions
+    const double *lut;             // Params::lut
+    int32_t N, RW, W, H, D, dyn0_off, dyn1_off;
+};
+__host__ __device__ inline Early early_of(const Params &P) {
+    return Early{P.state, P.actions, P.lut, P.N, P.RW, P.W, P.H, P.D, P.dyn0_off, P.dyn1_off};
+}
+
 template <int OPL, int CPL, int NA, int SCHEME, bool FUSED>
-__global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(const Params P) {
+__global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
+                                                          int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
+                                                          int32_t e_dyn1, const Params P0) {
+    Params P = P0;
+    P.state = e_state; P.actions = e_actions; P.lut = e_lut; P.N = e_N; P.RW = e_RW; P.W = e_W; P.H = e_H; P.D = e_D;
+    P.dyn0_off = e_dyn0; P.dyn1_off = e_dyn1;
     __shared__ Lds lds_all[ENVS_PER_WG];
     __shared__ double lut[LUT_SIZE];
     const int lane = (int)(threadIdx.x & 63u);
@@ -525,13 +543,17 @@ struct Inst {
     template <int NA>
     static hipError_t step_na(const Params &P, hipStream_t st) {
         const dim3 grid((unsigned)((P.N + ENVS_PER_WG - 1) / ENVS_PER_WG)), block(64 * ENVS_PER_WG);
+        const Early E = early_of(P);
+#define CZ_LAUNCH_STEP(S, F) \
+    hipLaunchKernelGGL((k_step<OPL, CPL, NA, S, F>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, P)
         if (P.actions) {
-            if (P.scheme == 3) hipLaunchKernelGGL((k_step<OPL, CPL, NA, 3, false>), grid, block, 0, st, P);
-            else hipLaunchKernelGGL((k_step<OPL, CPL, NA, 1, false>), grid, block, 0, st, P);
+            if (P.scheme == 3) CZ_LAUNCH_STEP(3, false);
+            else CZ_LAUNCH_STEP(1, false);
         } else {
-            if (P.scheme == 3) hipLaunchKernelGGL((k_step<OPL, CPL, NA, 3, true>), grid, block, 0, st, P);
-            else hipLaunchKernelGGL((k_step<OPL, CPL, NA, 1, true>), grid, block, 0, st, P);
+            if (P.scheme == 3) CZ_LAUNCH_STEP(3, true);
+            else CZ_LAUNCH_STEP(1, true);
         }
+#undef CZ_LAUNCH_STEP
         return hipGetLastError();
     }
     static hipError_t step(const Params &P, hipStream_t st) {
