@@ -22,6 +22,20 @@ namespace cz {
 #define CZ_STAMP(i) do { } while (0)
 #endif
 
+// Parameters that are needed late (output pointers, statistics, the reward constants of the rare "a recipe node changed"
+// path, the layout pool of the reset path) are read from the argument segment where they are used, through a pointer the
+// optimiser cannot see through -- otherwise every one of them is fetched at kernel entry and held in SGPRs for the whole
+// kernel (~30 SGPRs: spills in the non-fused kernel, ~90 spilled SGPRs in the fused one).
+typedef const __attribute__((address_space(4))) Params *KParams;
+struct StepArgsMirror { uint32_t *a; const int32_t *b; const double *c; int32_t i[7]; Params p; };   // k_step's argument list
+__device__ __forceinline__ KParams late_params(unsigned offset) {
+    const __attribute__((address_space(4))) char *k =
+        (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));                      // loads through the result stay behind this point
+    return reinterpret_cast<KParams>(k + offset);
+}
+#define CZ_LATE_STEP() late_params((unsigned)offsetof(StepArgsMirror, p))
+
 // LDS image of one env (halfwords, cooking_zoo_amd/soa.py IMG_*): every halfword is a BYTE offset into `lut`
 constexpr int IMG_OBJ0 = 0, IMG_CELL0 = 768, IMG_AG0 = 1792, IMG_ZERO = 1824, IMG_HALFWORDS = 1832;
 constexpr int LUT_ABSENT = 255, LUT_SIZE = 256;
@@ -287,7 +301,7 @@ struct StepOut {
 
 // One accumulated_step (cooking_env.py:243-269) of one env held in registers.
 template <int OPL, int CPL, int NA, int SCHEME>
-__device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t acts,
+__device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t acts,
                                          int64_t env_global, uint32_t &rowv, Lds &lds, uint32_t (&dsc)[OBS_CHUNK], Dirty &dt, StepOut &o) {
     using O = Ops<OPL, CPL, NA, SCHEME>;
     o.myrew = 0.0;
@@ -298,7 +312,7 @@ __device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, 
             e.episode += 1;
             uint32_t lay = next_layout(env_global, e.episode, e.pool, (uint32_t)P.L);
             uint32_t recipes = e.recipes, episode = e.episode, pool = e.pool;
-            load_env(P, e, cx, P.lay_init + (size_t)lay * P.RW);
+            load_env(P, e, cx, late_params(kp_off)->lay_init + (size_t)lay * P.RW);
             e.t = 0; e.layout = lay; e.status = 0; e.episode = episode; e.recipes = recipes; e.pool = pool;
             e.marks = all_marks(P, e, cx, rowv, lds);
             if (P.obs) load_desc(P, lay, 0, cx.lane, dsc);
@@ -353,11 +367,12 @@ __device__ __forceinline__ void step_env(const Params &P, Env<OPL, CPL, NA> &e, 
                 const int goals_before = __popc(~mb_r & countmask), goals_after = __popc(~ma & countmask);
                 const bool completed = ma & 1, completion_before = mb_r & 1;
                 const bool malus = !completed && completion_before, bonus = completed && !completion_before;
+                const KParams kp = late_params(kp_off);
                 double x = 0.0;
-                x += (double)(goals_before - goals_after) * P.node_reward;
-                x += (bonus ? 1.0 : 0.0) * P.recipe_reward;
-                x += (malus ? 1.0 : 0.0) * P.recipe_penalty;
-                x += P.time_penalty_step;
+                x += (double)(goals_before - goals_after) * kp->node_reward;
+                x += (bonus ? 1.0 : 0.0) * kp->recipe_reward;
+                x += (malus ? 1.0 : 0.0) * kp->recipe_penalty;
+                x += kp->time_penalty_step;
                 if (cx.lane == r && r < NA) o.myrew = x;                   // recipe r is agent r's (cooking_env.py:255-261)
             }
         }
@@ -434,14 +449,29 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(uint32_t *e_state, co
     const int T = FUSED ? P.T : 1;
 #pragma nounroll
     for (int t = 0; t < T; ++t) {
+        // The fused kernel re-reads its argument block every step (scalar loads that hit the constant cache): nothing of
+        // it then stays live across the loop's back edge, which is what used to spill ~90 SGPRs.
+        Params Pt;
+        if (FUSED) {
+            static_assert(sizeof(Params) % 8 == 0, "copied as 64-bit words");
+            typedef uint64_t __attribute__((may_alias)) word_t;
+            const __attribute__((address_space(4))) word_t *src = (const __attribute__((address_space(4))) word_t *)CZ_LATE_STEP();
+            word_t *dst = reinterpret_cast<word_t *>(&Pt);
+#pragma unroll
+            for (unsigned i = 0; i < sizeof(Params) / 8; ++i) dst[i] = src[i];
+            Pt.state = e_state; Pt.actions = e_actions; Pt.lut = e_lut; Pt.N = e_N; Pt.RW = e_RW; Pt.W = e_W; Pt.H = e_H; Pt.D = e_D;
+            Pt.dyn0_off = e_dyn0; Pt.dyn1_off = e_dyn1;
+        } else {
+            Pt = P;
+        }
         uint32_t acts;                                             // lane a = action of agent a
         if (!FUSED) acts = (uint32_t)av;
-        else acts = action_hash(P.seed, env_global, lane & 3, P.step0 + (uint32_t)t, SCHEME == 3 ? 5u : 8u);
+        else acts = action_hash(Pt.seed, env_global, lane & 3, Pt.step0 + (uint32_t)t, SCHEME == 3 ? 5u : 8u);
         Dirty dt{};
         StepOut o;
-        step_env<OPL, CPL, NA, SCHEME>(P, e, cx, acts, env_global, rowv, lds, dsc, dt, o);
+        step_env<OPL, CPL, NA, SCHEME>(Pt, (unsigned)offsetof(StepArgsMirror, p), e, cx, acts, env_global, rowv, lds, dsc, dt, o);
 #if defined(CZ_ABLATE)
-        if (P.stop == 2 || P.stop == 3) return;
+        if (Pt.stop == 2 || Pt.stop == 3) return;
 #endif
         CZ_STAMP(4);
         cells_dirty |= dt.cells != 0;
@@ -449,9 +479,10 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(uint32_t *e_state, co
         // ---- running return (lane a = agent a) and, at episode end only, the per-env statistics
         const double myrew = o.myrew;
         if (o.stepped) ret += myrew;
+        const KParams kp = CZ_LATE_STEP();
         if (o.finished) {
-            uint32_t *su = P.stat_u + (size_t)env * SU_WORDS;
-            double *sf = P.stat_f + (size_t)env * SF_WORDS;
+            uint32_t *su = kp->stat_u + (size_t)env * SU_WORDS;
+            double *sf = kp->stat_f + (size_t)env * SF_WORDS;
             if (lane == 0) {
                 su[SU_EPISODES] += 1; su[SU_LENSUM] += e.t; su[SU_TRUNC] += o.trunc; su[SU_TERM] += o.term;
             }
@@ -462,18 +493,23 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(uint32_t *e_state, co
             ret = 0.0;
         }
         // ---- outputs of this step
-        const size_t row = FUSED ? ((size_t)t * P.N + env) : (size_t)env;
+        const size_t row = FUSED ? ((size_t)t * Pt.N + env) : (size_t)env;
         if (lane < NA) {
-            if (P.rewards) stg<double>(P.rewards + row * NA, (uint32_t)lane * 8u, myrew);
-            if (P.term) stg<uint8_t>(P.term + row * NA, (uint32_t)lane, (uint8_t)o.term);
-            if (P.trunc) stg<uint8_t>(P.trunc + row * NA, (uint32_t)lane, (uint8_t)o.trunc);
+            double *const rewards = kp->rewards;
+            uint8_t *const term = kp->term, *const trunc = kp->trunc;
+            if (rewards) stg<double>(rewards + row * NA, (uint32_t)lane * 8u, myrew);
+            if (term) stg<uint8_t>(term + row * NA, (uint32_t)lane, (uint8_t)o.term);
+            if (trunc) stg<uint8_t>(trunc + row * NA, (uint32_t)lane, (uint8_t)o.trunc);
         }
-        if (!FUSED && P.marks_out && lane == 0) P.marks_out[env] = e.marks;     // infos["recipe_done"] of the host API
+        if (!FUSED) {
+            uint32_t *const marks_out = kp->marks_out;
+            if (marks_out && lane == 0) marks_out[env] = e.marks;               // infos["recipe_done"] of the host API
+        }
         CZ_STAMP(5);
         img_objs |= (dt.touched | dt.moved) != 0;
         img_cells |= dt.cells != 0;
-        if (P.obs) {
-            observe(P, e, cx, lds, lut, dsc, P.obs + row * (size_t)NA * P.F, img_objs, img_cells);
+        if (Pt.obs) {
+            observe(Pt, e, cx, lds, lut, dsc, Pt.obs + row * (size_t)NA * Pt.F, img_objs, img_cells);
             img_objs = false; img_cells = false;
         }
         CZ_STAMP(6);
