@@ -434,22 +434,24 @@ struct Ops {
         }
     }
 
-    // gather the byte of cell `c` (per-lane index) from the lanes that own the cells
-    static __device__ __forceinline__ uint32_t cell_gather(const E &e, uint32_t c) {
-        if (CPL == 1) return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)e.cell[0]);
-        uint32_t v = 0;
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-            uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((c & 63u) << 2), (int)e.cell[k]);
-            if ((c >> 6) == (uint32_t)k) v = t;
-        }
-        return v;
-    }
-
     // action_scheme3.py:4-43 / action_scheme1.py:4-40 perform_agent_actions (+ check_inbounds
     // cooking_world.py:192-204, check_collisions :206-221).  `act` : lane a = raw action of agent a.
     // The pre-pass and both filters run for all agents at once (lane a = agent a); the execution loop is serial
     // in agent order (action_scheme3.py:15-16) and pulls one agent out of the vectors with v_readlane.
+    // bit `c` of a cell-set mask, per lane
+    static __device__ __forceinline__ bool cell_bit(const CM &m, uint32_t c) {
+        uint64_t w = m.w[0];
+#pragma unroll
+        for (int k = 1; k < CPL; ++k)
+            if ((c >> 6) == (uint32_t)k) w = m.w[k];
+        return ((w >> (c & 63u)) & 1ull) != 0ull;
+    }
+    // the value of lane `lane ^ 1` / of the next lanes of the quad (agents live in lanes 0..3: DPP, no LDS, no SGPR trip)
+    template <int CTRL>
+    static __device__ __forceinline__ uint32_t quad(uint32_t v) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+    }
+
     static __device__ __forceinline__ void perform_agent_actions(E &e, const Ctx &cx, uint32_t act, Dirty &dt) {
         const uint32_t W = (uint32_t)cx.W, H = (uint32_t)cx.H;
         uint32_t x = e.agw & 0xFFu, y = (e.agw >> 8) & 0xFFu, o = (e.agw >> 16) & 0xFFu;
@@ -463,17 +465,27 @@ struct Ops {
         if (tx >= W || ty >= H) { act = 0; tx = x; ty = y; }
         const uint32_t own = y * W + x;
         uint32_t c = ty * W + tx;
-        const uint32_t ocv = cell_gather(e, own);
-        uint32_t tcv = cell_gather(e, c);
-        const bool wk = walkable(tcv);
-        // check_collisions: an agent is cancelled iff its end cell equals another agent's end cell and its own
-        // target was walkable.  count how many agents (including itself) end on this lane's end cell
-        const uint32_t exy = !live ? (0xFFFF0000u | (uint32_t)cx.lane) : wk ? (tx | (ty << 8)) : (x | (y << 8));
-        uint32_t cnt = 0;
+        // walkable cells and Switch cells as wave-uniform cell sets: what an agent lane needs to know about its target
+        // and its own cell is a bit test (the cell bytes live in the cell lanes; a ballot is cheaper than two LDS permutes)
+        CM walk_set, switch_set;
 #pragma unroll
-        for (int b = 0; b < NA; ++b) cnt += (exy == rdl(exy, b)) ? 1u : 0u;
-        if (NA > 1 && cnt > 1u && wk && act != 0u) { act = 0; tx = x; ty = y; c = own; tcv = ocv; }   // now "walks" onto its own cell
+        for (int k = 0; k < CPL; ++k) {
+            walk_set.w[k] = ballot(walkable(e.cell[k]));
+            switch_set.w[k] = ballot((e.cell[k] & CELL_TYPE) == SWITCH);
+        }
+        const bool wk = cell_bit(walk_set, c);
+        // check_collisions: an agent is cancelled iff its end cell equals another agent's end cell and its own
+        // target was walkable.  Non-agents carry a value nobody else has.
         const bool is_agent = cx.lane < NA && live;
+        const uint32_t exy = !is_agent ? (0xFFFF0000u | (uint32_t)cx.lane) : (wk ? (tx | (ty << 8)) : (x | (y << 8)));
+        // (every DPP move runs with all lanes enabled: a lane switched off by a short-circuit would read as 0 elsewhere)
+        bool clash = false;
+        if (NA == 2) clash = exy == quad<0xB1>(exy);                                            // lanes 0 <-> 1
+        if (NA > 2) {                                                                           // the other three lanes of the quad
+            const uint32_t r1 = quad<0x39>(exy), r2 = quad<0x4E>(exy), r3 = quad<0x93>(exy);
+            clash = (exy == r1) | (exy == r2) | (exy == r3);
+        }
+        if (NA > 1 && clash && wk && act != 0u) { act = 0; tx = x; ty = y; c = own; }   // now "walks" onto its own cell
         if (is_agent) e.agw = (e.agw & 0xFF00FFFFu) | (o << 16);              // lanes >= NA stay 0 (unused agent words)
         // ---- execution.  The reference resolves agents one after the other (action_scheme3.py:15-16), but a walking
         // agent only changes its own position, the position of what it carries and Switch bits, while an interacting
@@ -492,7 +504,7 @@ struct Ops {
             move_obj(e, cx, (int)(A >> 24) - 1, A & 0xFFFFu);
             dt.moved = 1;
         }
-        uint64_t press = ballot(walks && (tcv & CELL_TYPE) == SWITCH);     // Switch.add_content world_objects.py:159-163
+        uint64_t press = ballot(walks && cell_bit(switch_set, c));         // Switch.add_content world_objects.py:159-163
         while (press) {
             const int a = __ffsll((unsigned long long)press) - 1;
             press &= press - 1;

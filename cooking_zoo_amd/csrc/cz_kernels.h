@@ -103,17 +103,21 @@ __device__ __forceinline__ void load_env(const Params &P, Env<OPL, CPL, NA> &e, 
 // header + agents in one 12-lane store (v_writelane assembles the words), cells / objects only when they changed
 template <int OPL, int CPL, int NA>
 __device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t *__restrict__ rec,
-                                          bool cells_dirty, bool objs_dirty) {
+                                          bool cells_dirty, bool objs_dirty, bool header_dirty = true) {
     const uint32_t lane = (uint32_t)cx.lane;
-    uint32_t h = 0;
-    h = wrl(e.t, W_T, h);
-    h = wrl(e.marks, W_MARKS, h);
-    h = wrl(e.layout, W_LAYOUT, h);
-    h = wrl(e.status, W_STATUS, h);
-    h = wrl(e.episode, W_EPISODE, h);
-    h = wrl(e.recipes, W_RECIPES, h);
-    h = wrl(e.pool, W_POOL, h);
-    if (lane < (uint32_t)HDR_WORDS) stg<uint32_t>(rec, lane * 4u, h);
+    if (header_dirty) {
+        uint32_t h = 0;
+        h = wrl(e.t, W_T, h);
+        h = wrl(e.marks, W_MARKS, h);
+        h = wrl(e.layout, W_LAYOUT, h);
+        h = wrl(e.status, W_STATUS, h);
+        h = wrl(e.episode, W_EPISODE, h);
+        h = wrl(e.recipes, W_RECIPES, h);
+        h = wrl(e.pool, W_POOL, h);
+        if (lane < (uint32_t)HDR_WORDS) stg<uint32_t>(rec, lane * 4u, h);
+    } else if (lane == 0u) {
+        stg<uint32_t>(rec, W_T * 4u, e.t);                          // the step counter is all that changed (the usual case)
+    }
     if (lane < (uint32_t)MAX_AGENTS) stg<uint32_t>(rec, (AGENT_WORD0 + lane) * 4u, e.agw);
     if (cells_dirty) {
 #pragma unroll
@@ -297,6 +301,7 @@ struct StepOut {
     double myrew;                  // lane a < NA: the reward of agent a (cooking_env.py:255-261); 0.0 on the other lanes
     uint32_t term, trunc;
     bool stepped, finished;        // a world step was executed / it ended the episode
+    bool header;                   // a header word other than `t` changed (marks, status, episode, layout)
 };
 
 // One accumulated_step (cooking_env.py:243-269) of one env held in registers.
@@ -305,8 +310,9 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
                                          int64_t env_global, uint32_t &rowv, Lds &lds, uint32_t (&dsc)[OBS_CHUNK], Dirty &dt, StepOut &o) {
     using O = Ops<OPL, CPL, NA, SCHEME>;
     o.myrew = 0.0;
-    o.term = 0; o.trunc = 0; o.stepped = false; o.finished = false;
+    o.term = 0; o.trunc = 0; o.stepped = false; o.finished = false; o.header = false;
     if (e.status & ST_DONE) {
+        o.header = true;
         if (P.auto_reset) {
             // next-step autoreset: reset() of cooking_env.py:178-210 from the layout pool
             e.episode += 1;
@@ -378,6 +384,7 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
         }
     }
     e.marks = after;
+    o.header = after != before;
     // recipe roots are bit 0 of each marks byte
     const uint32_t roots = after & 0x01010101u & (P.R >= 4 ? 0xFFFFFFFFu : ((1u << (8 * P.R)) - 1u));
     const bool done = P.end_all ? (__popc(roots) == P.R) : (roots != 0u);
@@ -386,6 +393,7 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
     if (done || truncated) {
         e.status |= ST_DONE | (done ? ST_TERM : 0u) | (truncated ? ST_TRUNC : 0u);
         o.finished = true;
+        o.header = true;
     }
 }
 
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(uint32_t *e_state, co
     uint32_t dsc[OBS_CHUNK];
     if (P.obs) load_desc(P, e.layout, 0, lane, dsc);
     const int64_t env_global = P.env_id_base + env;
-    bool cells_dirty = false, objs_dirty = false;
+    bool cells_dirty = false, objs_dirty = false, header_dirty = FUSED;
     bool img_objs = true, img_cells = true;                 // which parts of the LDS image the next encode must rebuild
     if (threadIdx.x < (unsigned)LUT_SIZE) lut[threadIdx.x] = lutv;
     __syncthreads();
@@ -476,6 +484,7 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(uint32_t *e_state, co
         CZ_STAMP(4);
         cells_dirty |= dt.cells != 0;
         objs_dirty |= (dt.touched | dt.interacted | dt.moved) != 0;
+        header_dirty |= o.header;
         // ---- running return (lane a = agent a) and, at episode end only, the per-env statistics
         const double myrew = o.myrew;
         if (o.stepped) ret += myrew;
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(uint32_t *e_state, co
         }
         CZ_STAMP(6);
     }
-    store_env(P, e, cx, rec, cells_dirty, objs_dirty);
+    store_env(P, e, cx, rec, cells_dirty, objs_dirty, header_dirty);
     if (lane < NA) stg<double>(retp, (uint32_t)lane * 8u, ret);
     CZ_STAMP(7);
 }
