@@ -204,8 +204,8 @@ def worker(args):
     # inputs resident in HBM: a ring of int32 [N, A] action tensors, one slot per step (uniform over the 5 scheme3
     # actions); outputs: obs f64 [N, A, F], rewards f64, terminations / truncations u8.  The ring holds a whole number of
     # K-step runs so that every timed region replays one of a few graphs of exactly K launches.
-    runs_in_ring = max(1, 256 // K) if K <= 1024 else 1
-    period = K * runs_in_ring if K <= 1024 else 256
+    runs_in_ring = max(1, 256 // K) if K <= 256 else 1
+    period = K * runs_in_ring if K <= 256 else 256
     rng = np.random.default_rng(1234 + rank)
     d_actions = env.alloc((period, N, 2), np.int32)
     d_actions.from_host(rng.integers(0, 5, size=(period, N, 2), dtype=np.int32))
@@ -222,7 +222,7 @@ def worker(args):
         _native.check(h, L.cz_step_device_ring(h, k, *ring, first_slot % period, *outs))
 
     def first_slot_of(r):
-        return (r % runs_in_ring) * K if K <= 1024 else 0
+        return (r % runs_in_ring) * K if K <= 256 else 0
 
     # one-off graph captures outside the measurement (nothing is stepped)
     if Wm > 0:
@@ -329,7 +329,7 @@ def worker(args):
         achieved = b_alg * N / (kernel_med * 1e-6) / 1e9
         total_k = g_k.value + d_k.value
         api = (f"cz_step_device_ring: one kernel launch per env step; of the {total_k} timed launches {g_k.value} were replayed "
-               f"from HIP graphs of {K if K <= 1024 else 'up to 1024'} launches and {d_k.value} launched directly; "
+               f"from HIP graphs of {K if K <= 256 else 'up to 256'} launches and {d_k.value} launched directly; "
                f"actions/obs/rewards/flags resident in HBM")
         line = {
             "metric": "env-steps/sec at N parallel envs (1/2/4/8 GPU) + achieved HBM GB/s",

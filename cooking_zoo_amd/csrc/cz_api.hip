@@ -29,22 +29,31 @@ __global__ __launch_bounds__(64) void k_stats_chains(const uint32_t *__restrict_
                                                      const uint32_t *__restrict__ state, int RW, int N,
                                                      unsigned long long *__restrict__ part /* [256][16] */) {
     const int chain = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 4), col = (int)threadIdx.x & 15;
+    // which word of the per-env counters this lane's column sums (branch-free loop body: every load of a batch of envs is
+    // issued before anything is added, so the chain pays one memory round trip per batch, not per env)
+    const int widx = col == 0 ? (int)SU_STEPS : col == 1 ? (int)SU_EPISODES : col == 2 ? (int)SU_LENSUM : col == 3 ? (int)SU_TRUNC
+                   : col == 4 ? (int)SU_TERM : col < 9 ? (int)SU_COMPLETED0 + col - 5 : 0;
+    const int fidx = (col >= 9 && col < STAT_COLS) ? (int)SF_SUM0 + col - 9 : (int)SF_SUM0;
     unsigned long long acc = 0;
     double ret = 0.0;
-#pragma unroll 4
-    for (int e = chain; e < N; e += STAT_CHAINS) {
-        const uint32_t *p = su + (size_t)e * SU_WORDS;
-        if (col == 0) {
+    constexpr int B = 8;
+    for (int e0 = chain; e0 < N; e0 += STAT_CHAINS * B) {
+        uint32_t a[B], len[B], st[B], t[B];
+        double f[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            const int e = min(e0 + j * STAT_CHAINS, N - 1);                    // clamped: the value is dropped below
+            const uint32_t *p = su + (size_t)e * SU_WORDS;
             const uint32_t *rec = state + (size_t)e * RW;
-            const long long steps = (long long)(int)p[SU_STEPS] + (long long)p[SU_LENSUM] + ((rec[W_STATUS] & ST_DONE) ? 0 : (long long)rec[W_T]);
-            acc += (unsigned long long)steps;
-        } else if (col < 5) {
-            const int w = col == 1 ? SU_EPISODES : col == 2 ? SU_LENSUM : col == 3 ? SU_TRUNC : SU_TERM;
-            acc += p[w];
-        } else if (col < 9) {
-            acc += p[SU_COMPLETED0 + col - 5];
-        } else if (col < STAT_COLS) {
-            ret += sf[(size_t)e * SF_WORDS + SF_SUM0 + col - 9];
+            a[j] = p[widx]; len[j] = p[SU_LENSUM]; st[j] = rec[W_STATUS]; t[j] = rec[W_T];
+            f[j] = sf[(size_t)e * SF_WORDS + fidx];
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            if (e0 + j * STAT_CHAINS >= N) break;
+            const long long steps = (long long)(int)a[j] + (long long)len[j] + ((st[j] & ST_DONE) ? 0 : (long long)t[j]);
+            acc += col == 0 ? (unsigned long long)steps : (unsigned long long)a[j];
+            ret += f[j];                                                        // env order within the chain: fixed
         }
     }
     part[(size_t)chain * 16 + col] = (col >= 9 && col < STAT_COLS) ? (unsigned long long)__double_as_longlong(ret) : acc;
@@ -620,7 +629,7 @@ extern "C" int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_acti
 // where the ring wraps and at RING_MAX_GRAPH launches; pieces shorter than RING_MIN_GRAPH are launched directly.  At
 // most RING_CACHE graphs are kept (least recently used goes first), so a caller that keeps asking for new (slot, length)
 // pairs pays a capture each time -- keep the runs of a loop aligned.  Results are identical to cz_step_device_many.
-constexpr int RING_MIN_GRAPH = 4, RING_MAX_GRAPH = 1024, RING_CACHE = 64;
+constexpr int RING_MIN_GRAPH = 4, RING_MAX_GRAPH = 256, RING_CACHE = 64;   // (rocprofv3 --kernel-trace aborts on replays of ~1000 kernel nodes: malformed AQL packet)
 // captures the launches of slots [slot, slot + len) (nothing executes) and instantiates them
 static int ring_capture(cz_handle h, Params &P, const int32_t *d_ring, int64_t stride, int32_t slot, int32_t len, hipGraphExec_t &ge) {
     hipGraph_t g = nullptr;

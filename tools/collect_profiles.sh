@@ -1,15 +1,22 @@
 #!/bin/bash
 # GPU box: rocprofv3 evidence for bench.py's workload.  usage: bash tools/collect_profiles.sh TAG
 # (kernel trace + stats in one run; FETCH_SIZE and WRITE_SIZE in separate --pmc passes, as the microarch guide prescribes)
+# Every profiled command runs under `timeout`: a profiler-side abort must not be able to hold the box.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-cur}
 O=gpurun_out/prof_$TAG
+TRACE_ARGS=${TRACE_ARGS:---steps 400 --warmup 40 --repeats 5}
+PMC_ARGS="--steps 40 --warmup 10 --repeats 3"
 mkdir -p $O/trace $O/fetch $O/write $O/insts
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline > $O/bench_under_trace.json 2> $O/trace.log
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAVES --output-format csv -d $O/insts -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
-python3 bench.py > $O/bench.json 2> $O/bench.err
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py $TRACE_ARGS --no-cpu-baseline > $O/bench_under_trace.json 2> $O/trace.log
+echo "trace rc=$?"
+timeout 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py $PMC_ARGS --no-cpu-baseline > /dev/null 2>&1
+echo "fetch rc=$?"
+timeout 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py $PMC_ARGS --no-cpu-baseline > /dev/null 2>&1
+echo "write rc=$?"
+timeout 240 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAVES --output-format csv -d $O/insts -- python3 bench.py $PMC_ARGS --no-cpu-baseline > /dev/null 2>&1
+echo "insts rc=$?"
+timeout 600 python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 tools/trace_gaps.py $O/trace > $O/trace_gaps.txt
 python3 - <<PY
 import csv, glob, json, collections
