@@ -66,6 +66,8 @@ SYMBOLS = [
     ("cz_next_layout", _U32, [_I64, _U32, _U32, _U32]),
     ("cz_dev_alloc", _VP, [_VP, C.c_size_t]),
     ("cz_dev_free", C.c_int, [_VP, _VP]),
+    ("cz_host_alloc", _VP, [_VP, C.c_size_t]),
+    ("cz_host_free", C.c_int, [_VP, _VP]),
     ("cz_memcpy_h2d", C.c_int, [_VP, _VP, _VP, C.c_size_t]),
     ("cz_memcpy_d2h", C.c_int, [_VP, _VP, _VP, C.c_size_t]),
     ("cz_timer_start", C.c_int, [_VP]),

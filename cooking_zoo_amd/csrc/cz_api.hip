@@ -135,9 +135,10 @@ struct cz_handle_s {
     double *d_lut = nullptr;
     // staging for the host-pointer API
     int32_t *d_actions = nullptr;
-    double *d_obs = nullptr, *d_rew = nullptr;
-    uint8_t *d_term = nullptr, *d_trunc = nullptr;
-    uint32_t *d_marks = nullptr, *marks_out_next = nullptr;   // (cz_step hands the kernel a marks buffer for one launch)
+    double *d_obs = nullptr;
+    char *d_small = nullptr, *h_small = nullptr;   // rewards | terminations | truncations | marks: one device block, one pinned block
+    uint32_t *h_marks = nullptr, *d_marks_mapped = nullptr;   // pinned, device-mapped marks buffer of the direct path
+    uint32_t *marks_out_next = nullptr;            // (cz_step hands the kernel a marks buffer for one launch)
     std::vector<uint32_t> last_marks;          // recipe marks after the most recent cz_step (cz_last_marks)
     char *h_stage = nullptr, *d_stage = nullptr;   // small batches: pinned, device-mapped staging block of cz_step
     // cz_step_device_ring: which ring / output buffers / tables the cached graphs were captured for
@@ -316,12 +317,14 @@ extern "C" int cz_destroy(cz_handle h) {
         if (f) f(h->comm);
     }
     void *ptrs[] = {h->d_lut, h->d_state, h->d_lay_init, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out, h->d_stats_part,
-                    h->d_actions, h->d_obs, h->d_rew, h->d_term, h->d_trunc, h->d_gather, h->d_marks};
+                    h->d_actions, h->d_obs, h->d_small, h->d_gather};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &r : h->ring_graphs)
         if (r.ge) (void)hipGraphExecDestroy(r.ge);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_small) (void)hipHostFree(h->h_small);
+    if (h->h_marks) (void)hipHostFree(h->h_marks);
     for (hipEvent_t e : h->kev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -757,6 +760,17 @@ extern "C" int cz_rollout(cz_handle h, int32_t T, uint64_t seed, uint32_t step0,
     return launch_step(h, P);
 }
 
+// the device address of pinned, device-mapped host memory (cz_host_alloc, hipHostMalloc, hipHostRegister); nullptr for
+// pageable memory
+static void *mapped_device_pointer(const void *host) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, host) != hipSuccess) {
+        (void)hipGetLastError();                      // pageable memory: "invalid value", not an error of ours
+        return nullptr;
+    }
+    return attr.type == hipMemoryTypeHost ? attr.devicePointer : nullptr;
+}
+
 extern "C" int cz_step(cz_handle h, const int32_t *actions, double *obs, double *rewards, uint8_t *term, uint8_t *trunc) {
     if (ready(h)) return 1;
     if (!actions || !rewards || !term || !trunc) return fail(h, "cz_step: null buffer");
@@ -795,27 +809,51 @@ extern "C" int cz_step(cz_handle h, const int32_t *actions, double *obs, double 
         h->last_marks.assign((const uint32_t *)(h->h_stage + o_marks), (const uint32_t *)(h->h_stage + o_marks) + h->P.N);
         return 0;
     }
+    // Buffers from cz_host_alloc (or any pinned, device-mapped host memory): the kernel reads the actions from and writes
+    // every output to them directly -- the observation bytes cross PCIe while the launch is still computing, and no copy
+    // command is queued at all.
+    {
+        void *d_act = mapped_device_pointer(actions), *d_rew = mapped_device_pointer(rewards), *d_term = mapped_device_pointer(term),
+             *d_trunc = mapped_device_pointer(trunc), *d_obs = obs ? mapped_device_pointer(obs) : nullptr;
+        if (d_act && d_rew && d_term && d_trunc && (!obs || d_obs)) {
+            if (!h->h_marks) {
+                HIPCHK(h, hipHostMalloc((void **)&h->h_marks, (size_t)h->P.N * 4, hipHostMallocMapped));
+                HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_marks_mapped, h->h_marks, 0));
+            }
+            h->marks_out_next = h->d_marks_mapped;
+            if (cz_step_device(h, (const int32_t *)d_act, (double *)d_obs, (double *)d_rew, (uint8_t *)d_term, (uint8_t *)d_trunc)) {
+                h->marks_out_next = nullptr;
+                return 1;
+            }
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            h->last_marks.assign(h->h_marks, h->h_marks + h->P.N);
+            return 0;
+        }
+    }
+    // Pageable buffers: staged copies.  The small outputs (rewards, flags, marks) live in one device block and come back
+    // with one copy command through one pinned block; the observation goes straight into the caller's array.
+    const size_t s_rew = 0, s_term = NA * 8, s_trunc = s_term + ((NA + 15) & ~(size_t)15), s_marks = s_trunc + ((NA + 15) & ~(size_t)15),
+                 s_total = s_marks + (size_t)h->P.N * 4;
     if (!h->d_actions) {
         HIPCHK(h, hipMalloc(&h->d_actions, NA * 4));
-        HIPCHK(h, hipMalloc(&h->d_rew, NA * 8));
-        HIPCHK(h, hipMalloc(&h->d_term, NA));
-        HIPCHK(h, hipMalloc(&h->d_trunc, NA));
-        HIPCHK(h, hipMalloc(&h->d_marks, (size_t)h->P.N * 4));
+        HIPCHK(h, hipMalloc(&h->d_small, s_total));
+        HIPCHK(h, hipHostMalloc((void **)&h->h_small, s_total, hipHostMallocDefault));
     }
     if (obs && !h->d_obs) HIPCHK(h, hipMalloc(&h->d_obs, ob));
     HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, NA * 4, hipMemcpyHostToDevice, h->stream));
-    h->marks_out_next = h->d_marks;
-    if (cz_step_device(h, h->d_actions, obs ? h->d_obs : nullptr, h->d_rew, h->d_term, h->d_trunc)) {
+    h->marks_out_next = (uint32_t *)(h->d_small + s_marks);
+    if (cz_step_device(h, h->d_actions, obs ? h->d_obs : nullptr, (double *)(h->d_small + s_rew), (uint8_t *)(h->d_small + s_term),
+                       (uint8_t *)(h->d_small + s_trunc))) {
         h->marks_out_next = nullptr;
         return 1;
     }
-    h->last_marks.resize((size_t)h->P.N);
-    HIPCHK(h, hipMemcpyAsync(h->last_marks.data(), h->d_marks, (size_t)h->P.N * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, s_total, hipMemcpyDeviceToHost, h->stream));
     if (obs) HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, ob, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(rewards, h->d_rew, NA * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(term, h->d_term, NA, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(trunc, h->d_trunc, NA, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    memcpy(rewards, h->h_small + s_rew, NA * 8);
+    memcpy(term, h->h_small + s_term, NA);
+    memcpy(trunc, h->h_small + s_trunc, NA);
+    h->last_marks.assign((const uint32_t *)(h->h_small + s_marks), (const uint32_t *)(h->h_small + s_marks) + h->P.N);
     return 0;
 }
 
@@ -859,6 +897,23 @@ extern "C" int cz_dev_free(cz_handle h, void *p) {
     if (!h) return fail(nullptr, "null handle");
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipFree(p));
+    return 0;
+}
+// Pinned (page-locked) host memory: buffers handed to cz_step / cz_reset / cz_observe from here are reached by the copy
+// engines directly, without the runtime pinning or staging pageable pages on every call.
+extern "C" void *cz_host_alloc(cz_handle h, size_t bytes) {
+    if (!h) return nullptr;
+    void *p = nullptr;
+    if (hipSetDevice(h->cfg.device_id) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        fail(h, "cz_host_alloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+extern "C" int cz_host_free(cz_handle h, void *p) {
+    if (!h) return fail(nullptr, "null handle");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipHostFree(p));
     return 0;
 }
 extern "C" int cz_memcpy_h2d(cz_handle h, void *d, const void *s, size_t n) {

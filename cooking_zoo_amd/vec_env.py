@@ -74,11 +74,16 @@ def resolve_recipe_tables(recipes):
 class CookingVecEnv:
     def __init__(self, num_envs, level, meta_file, num_agents, max_steps, recipes, end_condition_all_dishes=False,
                  action_scheme="scheme1", reward_scheme=None, *, num_layouts=256, layout_seed=0, layouts=None,
-                 auto_reset=True, device_id=0, env_id_base=0, max_dyn=None):
+                 auto_reset=True, device_id=0, env_id_base=0, max_dyn=None, pinned_outputs=False):
         """`level` may be one level name/path or a list (env e uses levels[e % len]); `recipes` is a list of
         names (every env the same) or an int array [num_envs, R] of indices into the recipe book.
         `layouts` (optional) supplies pre-instantiated Layout objects per level instead of drawing
-        `num_layouts` of them with random.Random(layout_seed)."""
+        `num_layouts` of them with random.Random(layout_seed).
+        `pinned_outputs=True`: `step` / `reset` / `observe` return views of page-locked host buffers owned by the env
+        (overwritten by the next call) instead of fresh arrays -- the copy engines then write them directly, which is what
+        a host-array step of thousands of envs spends its time on (18 MB of observations per step at 4096 envs)."""
+        self._pinned = bool(pinned_outputs)
+        self._pin_bufs = {}
         if action_scheme not in ACTION_SCHEMES:
             raise ValueError("action_scheme must be 'scheme1' or 'scheme3' (scheme2 raises AttributeError in the "
                              "reference: action_scheme2.py:15)")
@@ -182,22 +187,40 @@ class CookingVecEnv:
         else:
             ids = ids[env_begin:env_begin + n].copy()
         pools = np.ascontiguousarray(pools[env_begin:env_begin + n])
-        obs = np.empty((n, self.num_agents, self.F), dtype=np.float64) if return_obs else None
+        obs = self._host_array("obs", (n, self.num_agents, self.F), np.float64) if return_obs else None
         rid = np.ascontiguousarray(self.recipe_ids[env_begin:env_begin + n])
         _native.check(self._h, _native.lib().cz_reset(self._h, env_begin, n, _ptr(ids), _ptr(rid), _ptr(pools), _ptr(obs)))
         return obs
 
+    def _host_array(self, key, shape, dtype):
+        """a fresh array, or (pinned_outputs) the env's page-locked buffer of that role"""
+        if not self._pinned:
+            return np.empty(shape, dtype=dtype)
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        buf = self._pin_bufs.get(key)
+        if buf is None or buf[1] < nbytes:
+            if buf is not None:
+                _native.lib().cz_host_free(self._h, buf[0])
+            p = _native.lib().cz_host_alloc(self._h, max(nbytes, 1))
+            if not p:
+                _native.check(self._h, 1)
+            buf = self._pin_bufs[key] = (p, max(nbytes, 1))
+        raw = (C.c_uint8 * nbytes).from_address(buf[0])
+        return np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
     def step(self, actions, return_obs=True):
         """actions int [N, A] -> (obs f64 [N, A, F] | None, rewards f64 [N, A], terminations u8, truncations u8).
         An action of -1 means "this agent is despawned": it is left out of the step (cooking_world.py:105-108)."""
-        acts = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.num_envs, self.num_agents)
+        N, A = self.num_envs, self.num_agents
+        acts = self._host_array("act", (N, A), np.int32)
+        acts[...] = np.asarray(actions).reshape(N, A)
         if acts.size and int(acts.max()) >= self.n_actions:
             raise ValueError(f"actions must be in [0, {self.n_actions}) for {self.action_scheme} (negative = despawned agent)")
-        N, A = self.num_envs, self.num_agents
-        obs = np.empty((N, A, self.F), dtype=np.float64) if return_obs else None
-        rew = np.empty((N, A), dtype=np.float64)
-        term = np.empty((N, A), dtype=np.uint8)
-        trunc = np.empty((N, A), dtype=np.uint8)
+        obs = self._host_array("obs", (N, A, self.F), np.float64) if return_obs else None
+        rew = self._host_array("rew", (N, A), np.float64)
+        term = self._host_array("term", (N, A), np.uint8)
+        trunc = self._host_array("trunc", (N, A), np.uint8)
         _native.check(self._h, _native.lib().cz_step(self._h, _ptr(acts), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc)))
         return obs, rew, term, trunc
 
@@ -209,7 +232,7 @@ class CookingVecEnv:
 
     def observe(self, env_begin=0, env_count=None):
         n = self.num_envs if env_count is None else int(env_count)
-        obs = np.empty((n, self.num_agents, self.F), dtype=np.float64)
+        obs = self._host_array("obs", (n, self.num_agents, self.F), np.float64)
         _native.check(self._h, _native.lib().cz_observe(self._h, env_begin, n, _ptr(obs)))
         return obs
 
@@ -264,6 +287,9 @@ class CookingVecEnv:
         if getattr(self, "_h", None):
             for b in self._buffers:
                 b.free()
+            for p, _ in self._pin_bufs.values():
+                _native.lib().cz_host_free(self._h, p)
+            self._pin_bufs = {}
             _native.lib().cz_destroy(self._h)
             self._h = None
 

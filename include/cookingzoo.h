@@ -162,6 +162,10 @@ uint32_t cz_next_layout(int64_t env_global, uint32_t episode, uint32_t pool_word
 /* ---- device memory + timing helpers (so the Python host needs no torch) ----------------------------- */
 void *cz_dev_alloc(cz_handle h, size_t bytes);
 int cz_dev_free(cz_handle h, void *d_ptr);
+/* pinned host memory: host buffers taken from here (actions / observations / rewards / flags of cz_step, cz_reset,
+ * cz_observe) are written and read by the copy engines directly -- no per-call pinning or staging of pageable pages */
+void *cz_host_alloc(cz_handle h, size_t bytes);
+int cz_host_free(cz_handle h, void *ptr);
 int cz_memcpy_h2d(cz_handle h, void *d_dst, const void *src, size_t bytes);
 int cz_memcpy_d2h(cz_handle h, void *dst, const void *d_src, size_t bytes);
 int cz_timer_start(cz_handle h);                           /* hipEventRecord on the handle's stream */

@@ -151,3 +151,30 @@ def test_aec_env_matches_reference_trace(case):
         dead.step(0)                                  # truncated: only None is valid now
     e.close()
 
+
+
+def test_pinned_output_buffers_give_the_same_results():
+    """pinned_outputs=True: step / reset / observe fill page-locked buffers owned by the env (views, overwritten by the
+    next call); results equal the fresh-array path bit for bit, on the staged-copy path and the small zero-copy path."""
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    for n in (3, 700):
+        kw = dict(action_scheme="scheme3", num_layouts=4, auto_reset=True)
+        a = CookingVecEnv(n, "coop_test", "example", 2, 30, ["TomatoLettuceSalad", "CarrotBanana"], pinned_outputs=True, **kw)
+        b = CookingVecEnv(n, "coop_test", "example", 2, 30, ["TomatoLettuceSalad", "CarrotBanana"], **kw)
+        oa, ob = a.reset(), b.reset()
+        assert np.array_equal(oa.view(np.uint64), ob.view(np.uint64))
+        rng = np.random.default_rng(n)
+        first = None
+        for t in range(40):
+            acts = rng.integers(0, 5, size=(n, 2), dtype=np.int32)
+            ra, rb = a.step(acts), b.step(acts)
+            for x, y in zip(ra, rb):
+                assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), t
+            if first is None:
+                first = ra[0]
+        again_a, again_b = a.step(acts), b.step(acts)
+        assert first is not None and np.shares_memory(first, again_a[0])          # a view of the same pinned buffer
+        assert np.array_equal(again_a[0].view(np.uint64), again_b[0].view(np.uint64))
+        assert np.array_equal(a.observe().view(np.uint64), b.observe().view(np.uint64))
+        assert np.array_equal(a.get_state(), b.get_state())
+        a.close(); b.close()
