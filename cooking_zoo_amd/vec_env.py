@@ -74,16 +74,22 @@ def resolve_recipe_tables(recipes):
 class CookingVecEnv:
     def __init__(self, num_envs, level, meta_file, num_agents, max_steps, recipes, end_condition_all_dishes=False,
                  action_scheme="scheme1", reward_scheme=None, *, num_layouts=256, layout_seed=0, layouts=None,
-                 auto_reset=True, device_id=0, env_id_base=0, max_dyn=None, pinned_outputs=False):
+                 auto_reset=True, device_id=0, env_id_base=0, max_dyn=None, pinned_outputs=False,
+                 agent_respawn_rate=0.0, grace_period=20, agent_despawn_rate=0.0, spawn_seed=0):
         """`level` may be one level name/path or a list (env e uses levels[e % len]); `recipes` is a list of
         names (every env the same) or an int array [num_envs, R] of indices into the recipe book.
         `layouts` (optional) supplies pre-instantiated Layout objects per level instead of drawing
         `num_layouts` of them with random.Random(layout_seed).
         `pinned_outputs=True`: `step` / `reset` / `observe` return views of page-locked host buffers owned by the env
         (overwritten by the next call) instead of fresh arrays -- the copy engines then write them directly, which is what
-        a host-array step of thousands of envs spends its time on (18 MB of observations per step at 4096 envs)."""
+        a host-array step of thousands of envs spends its time on (18 MB of observations per step at 4096 envs).
+        `agent_despawn_rate` / `agent_respawn_rate` / `grace_period`: agent despawn / respawn (cooking_world.py:267-290)
+        for every world of the batch, host-side bookkeeping with keyed random streams (cooking_zoo_amd/spawn.py); only the
+        host-array `step` applies it."""
         self._pinned = bool(pinned_outputs)
         self._pin_bufs = {}
+        self._spawn_cfg = (float(agent_despawn_rate), float(agent_respawn_rate), int(grace_period), int(spawn_seed))
+        self.spawn = None
         if action_scheme not in ACTION_SCHEMES:
             raise ValueError("action_scheme must be 'scheme1' or 'scheme3' (scheme2 raises AttributeError in the "
                              "reference: action_scheme2.py:15)")
@@ -153,6 +159,16 @@ class CookingVecEnv:
         self._upload_layouts()
         self._buffers = []
         self.env_level = np.arange(self.num_envs) % len(self.levels)
+        if self._spawn_cfg[0] or self._spawn_cfg[1]:
+            from cooking_zoo_amd.spawn import SpawnBook
+            if len(self.levels) != 1:
+                raise ValueError("agent despawn / respawn needs one level per batch (the spawn areas come from the level file)")
+            cells = [(spec["X_POSITION"], spec["Y_POSITION"]) for spec in self.level_objects[0]["AGENTS"]
+                     for _ in range(spec["MAX_COUNT"])][:self.num_agents]                       # parsing.py:145
+            self.spawn = SpawnBook(self.num_envs, self.num_agents, cells, despawn_rate=self._spawn_cfg[0],
+                                   respawn_rate=self._spawn_cfg[1], grace_period=self._spawn_cfg[2], seed=self._spawn_cfg[3],
+                                   env_id_base=self.env_id_base)
+            self._episode_seen = None
 
     # ------------------------------------------------------------------ tables
     def _upload_layouts(self):
@@ -190,6 +206,11 @@ class CookingVecEnv:
         obs = self._host_array("obs", (n, self.num_agents, self.F), np.float64) if return_obs else None
         rid = np.ascontiguousarray(self.recipe_ids[env_begin:env_begin + n])
         _native.check(self._h, _native.lib().cz_reset(self._h, env_begin, n, _ptr(ids), _ptr(rid), _ptr(pools), _ptr(obs)))
+        if self.spawn is not None:
+            mask = np.zeros(self.num_envs, dtype=bool)
+            mask[env_begin:env_begin + n] = True
+            self.spawn.reset_envs(mask)
+            self._episode_seen = None if n == self.num_envs else self._episode_seen
         return obs
 
     def _host_array(self, key, shape, dtype):
@@ -217,12 +238,41 @@ class CookingVecEnv:
         acts[...] = np.asarray(actions).reshape(N, A)
         if acts.size and int(acts.max()) >= self.n_actions:
             raise ValueError(f"actions must be in [0, {self.n_actions}) for {self.action_scheme} (negative = despawned agent)")
+        if self.spawn is not None:
+            acts[...] = self.spawn.mask_actions(acts)                     # despawned agents do not act
         obs = self._host_array("obs", (N, A, self.F), np.float64) if return_obs else None
         rew = self._host_array("rew", (N, A), np.float64)
         term = self._host_array("term", (N, A), np.uint8)
         trunc = self._host_array("trunc", (N, A), np.uint8)
         _native.check(self._h, _native.lib().cz_step(self._h, _ptr(acts), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc)))
+        if self.spawn is not None:
+            self._spawn_after_step(obs, trunc)
         return obs, rew, term, trunc
+
+    def _spawn_after_step(self, obs, trunc):
+        """handle_agent_spawn (cooking_world.py:267-290) of every world that executed a world step in this launch; worlds
+        that were re-instantiated by it (auto-reset pass) start over with everybody present."""
+        recs = self.get_state()
+        episode = recs[:, soa.W_EPISODE].copy()
+        done_now = (recs[:, soa.W_STATUS] & soa.STATUS_DONE) != 0
+        if self._episode_seen is None:
+            fresh = was_done = np.zeros(self.num_envs, dtype=bool)
+        else:
+            fresh, was_done = episode != self._episode_seen[0], self._episode_seen[1]
+        self._episode_seen = (episode, done_now)
+        self.spawn.reset_envs(fresh)
+        moved = self.spawn.after_step(recs, self.dims, stepped=~fresh & ~was_done)
+        for e in moved:
+            self.set_state(recs[e:e + 1], env_begin=int(e))
+            if obs is not None:
+                obs[e] = self._observe_fresh(int(e))                     # somebody was put on a new cell
+        # whoever was despawned in this step is reported once, truncated (cooking_env.py:344-349)
+        trunc |= (self.spawn.changed & ~self.spawn.active).astype(np.uint8)
+
+    def _observe_fresh(self, e):
+        out = np.empty((1, self.num_agents, self.F), dtype=np.float64)
+        _native.check(self._h, _native.lib().cz_observe(self._h, e, 1, _ptr(out)))
+        return out[0]
 
     def last_marks(self):
         """Recipe-node marks (uint32 [N], bit 8r+j) after the most recent host-array `step`."""
