@@ -255,10 +255,10 @@ def worker(args):
     g_k, d_k = C.c_int64(), C.c_int64()
     L.cz_launch_counts(h, C.byref(g_k), C.byref(d_k), 0)
 
-    # dominant-kernel duration: HIP events on the kernels' own stream around max(R*K, 400) launches issued back to back (the
+    # dominant-kernel duration: HIP events on the kernels' own stream around max(R*K, 4000) launches issued back to back (the
     # host <-> GPU round trip of a synchronised region, ~20 us on this platform whatever K is, is not kernel time)
     ev_ms = C.c_float()
-    n_ev = max(R * K, 400)
+    n_ev = max(R * K, 4000)
     _native.check(h, L.cz_ring_prepare(h, n_ev, *ring, 0, *outs))
     barrier()
     L.cz_timer_start(h)
@@ -348,7 +348,7 @@ def worker(args):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(f"k_step_{N}"),
                          "kernel": "cz::k_step<1,1,2,3,false> (one wavefront per env, 8 envs per workgroup)",
-                         "kernel_us": kernel_med, "kernel_us_from": f"HIP events around {max(R * K, 400)} back-to-back launches on the kernels' stream",
+                         "kernel_us": kernel_med, "kernel_us_from": f"HIP events around {max(R * K, 4000)} back-to-back launches on the kernels' stream",
                          "alg_bytes_per_env_step": b_alg, "units_per_launch": N,
                          # measured on this box, same run: a kernel of the same grid shape that ONLY writes the observation
                          # bytes (write-through 16-byte stores); write-only traffic does not reach the 8 TB/s read+write peak

@@ -93,11 +93,15 @@ class Recipe:
     def completed(self):
         return bool(self.marks & 1)
 
-    def flatten(self) -> np.ndarray:
-        """-> uint32[1 + MAX_NODES]: n_nodes, then per node  cls | cond<<8 | child_mask<<16 | counts<<24.
-        `counts` marks the last node carrying a given goal id (goals[id] is overwritten by later nodes,
-        recipe.py:38-39, so only that one contributes to sum(goals))."""
-        out = np.zeros(1 + soa.MAX_NODES, dtype=np.uint32)
+    def flatten(self, max_nodes: int = soa.NARROW_NODES) -> np.ndarray:
+        """The node table row the kernels evaluate.  `counts` marks the last node carrying a given goal id (goals[id] is
+        overwritten by later nodes, recipe.py:38-39, so only that one contributes to sum(goals)).
+        max_nodes = 8  -> uint32[9]:  n_nodes, then per node  cls | cond<<8 | child_mask<<16 | counts<<24
+        max_nodes = 16 -> uint32[33]: n_nodes, then per node two words  cls | cond<<8 | counts<<24,  child_mask (16 bits)"""
+        if len(self.node_list) > max_nodes:
+            raise ValueError(f"recipe graph has {len(self.node_list)} nodes, the table row holds {max_nodes}")
+        wide = max_nodes > soa.NARROW_NODES
+        out = np.zeros(1 + (2 * soa.MAX_NODES if wide else soa.NARROW_NODES), dtype=np.uint32)
         out[0] = len(self.node_list)
         index = {id(n): j for j, n in enumerate(self.node_list)}
         last_with_id = {}
@@ -108,6 +112,9 @@ class Recipe:
             for c in n.contains:
                 child_mask |= 1 << index[id(c)]
             counts = 1 if last_with_id[n.id_num] == j else 0
-            out[1 + j] = (soa.class_node_id(n.name) | (_condition_code(n.conditions, n.name) << 8) | (child_mask << 16)
-                          | (counts << 24))
+            word = soa.class_node_id(n.name) | (_condition_code(n.conditions, n.name) << 8) | (counts << 24)
+            if wide:
+                out[1 + 2 * j], out[2 + 2 * j] = word, child_mask
+            else:
+                out[1 + j] = word | (child_mask << 16)
         return out

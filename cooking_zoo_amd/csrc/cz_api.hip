@@ -193,7 +193,7 @@ static int fail(cz_handle h, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *cz_last_error(cz_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
-extern "C" int32_t cz_abi_version(void) { return 2; }
+extern "C" int32_t cz_abi_version(void) { return 3; }
 // diagnostic builds only (tools/phase_profile.py): where the kernels write their s_memtime stamps
 extern "C" int cz_debug_set_stamps(cz_handle h, void *d_buf) {
     if (!h) return 1;
@@ -351,43 +351,56 @@ extern "C" int cz_sync(cz_handle h) {
     return 0;
 }
 
-extern "C" int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n) {
-    if (!h || !table || n < 1 || n > 255) return fail(h, "cz_load_recipes: bad arguments");
+// device encoding of one node (layout documented at Ops::recipe_marks in cz_device.h); `children` = 0 for wide rows
+static int encode_node(cz_handle h, int recipe, uint32_t j, uint32_t hw, uint32_t children, uint32_t *out) {
+    const uint32_t cls = hw & 0xFF, cond = (hw >> 8) & 0xFF, counts = (hw >> 24) & 1;
+    uint32_t w = children | (counts << 8);
+    if (cls < 16) {
+        w |= 0x200u | ((cls <= BLENDER ? cls : 7u) << 10);                  // unknown static class: matches nothing
+    } else if (cls < 32) {
+        // states: 0 fresh, 1 chopped, 2 mashed, 3 both.  Only Carrot / Banana have a blend_state (the reference
+        // raises AttributeError when a blend condition meets another class; here such a node matches nothing)
+        const bool blender_food = (cls - 16) == CARROT || (cls - 16) == BANANA;
+        uint32_t acc;
+        if (cond & 0x10u) acc = cond & 0xFu;                               // explicit accept mask (several conditions)
+        else if (cond == COND_NONE) acc = 0xFu;
+        else if (cond == COND_CHOPPED) acc = 0xAu;
+        else if (cond == COND_NOT_CHOPPED) acc = 0x5u;
+        else if (cond == COND_MASHED) acc = blender_food ? 0xCu : 0u;
+        else if (cond == COND_NOT_MASHED) acc = blender_food ? 0x3u : 0u;
+        else return fail(h, "cz_load_recipes: recipe %d node %u: unknown condition code %u", recipe, j, cond);
+        w |= 0x2000u | ((cls - 16) << 16) | (acc << 24);
+    }
+    // (any other class id, e.g. 255 for a name without objects such as "Agent": neither flag, matches nothing)
+    *out = w;
+    return 0;
+}
+
+extern "C" int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n, int32_t max_nodes) {
+    if (!h || !table || n < 1 || n > 255 || (max_nodes != MAX_NODES && max_nodes != WIDE_NODES)) return fail(h, "cz_load_recipes: bad arguments");
+    const bool wide = max_nodes == WIDE_NODES;
+    const size_t row_words = wide ? 1 + 2 * WIDE_NODES : 1 + MAX_NODES;
     for (int i = 0; i < n; ++i)
-        if (table[(size_t)i * (1 + MAX_NODES)] > MAX_NODES) return fail(h, "cz_load_recipes: recipe %d has more than 8 nodes", i);
+        if (table[(size_t)i * row_words] > (uint32_t)max_nodes) return fail(h, "cz_load_recipes: recipe %d has more than %d nodes", i, max_nodes);
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (h->d_recipes) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->d_recipes)); h->d_recipes = nullptr; h->P.recipes = nullptr; }
-    size_t bytes = (size_t)n * (1 + MAX_NODES) * 4;
+    size_t bytes = (size_t)n * row_words * 4;
     HIPCHK(h, hipMalloc(&h->d_recipes, bytes));
-    // device copy: word 0 = node count; node words are re-encoded for the kernels (layout documented at
-    // Ops::recipe_marks in cz_device.h): conditions become an accept mask over the state index chopped | mashed << 1
-    std::vector<uint32_t> dev(table, table + (size_t)n * (1 + MAX_NODES));
+    // device copy: word 0 = node count; node words are re-encoded for the kernels: conditions become an accept mask over
+    // the state index chopped | mashed << 1
+    std::vector<uint32_t> dev(table, table + (size_t)n * row_words);
     for (int i = 0; i < n; ++i) {
-        uint32_t *row = dev.data() + (size_t)i * (1 + MAX_NODES);
+        uint32_t *row = dev.data() + (size_t)i * row_words;
         const uint32_t nn = row[0];
-        for (uint32_t j = 0; j < MAX_NODES; ++j) {
-            const uint32_t hw = row[1 + j];
-            const uint32_t cls = hw & 0xFF, cond = (hw >> 8) & 0xFF, children = (hw >> 16) & 0xFF, counts = (hw >> 24) & 1;
-            uint32_t w = children | (counts << 8);
-            if (j >= nn) { row[1 + j] = 0; continue; }
-            if (cls < 16) {
-                w |= 0x200u | ((cls <= BLENDER ? cls : 7u) << 10);                  // unknown static class: matches nothing
-            } else if (cls < 32) {
-                // states: 0 fresh, 1 chopped, 2 mashed, 3 both.  Only Carrot / Banana have a blend_state (the reference
-                // raises AttributeError when a blend condition meets another class; here such a node matches nothing)
-                const bool blender_food = (cls - 16) == CARROT || (cls - 16) == BANANA;
-                uint32_t acc;
-                if (cond & 0x10u) acc = cond & 0xFu;                               // explicit accept mask (several conditions)
-                else if (cond == COND_NONE) acc = 0xFu;
-                else if (cond == COND_CHOPPED) acc = 0xAu;
-                else if (cond == COND_NOT_CHOPPED) acc = 0x5u;
-                else if (cond == COND_MASHED) acc = blender_food ? 0xCu : 0u;
-                else if (cond == COND_NOT_MASHED) acc = blender_food ? 0x3u : 0u;
-                else return fail(h, "cz_load_recipes: recipe %d node %u: unknown condition code %u", i, j, cond);
-                w |= 0x2000u | ((cls - 16) << 16) | (acc << 24);
+        for (uint32_t j = 0; j < (uint32_t)max_nodes; ++j) {
+            if (wide) {
+                if (j >= nn) { row[1 + 2 * j] = row[2 + 2 * j] = 0; continue; }
+                if (encode_node(h, i, j, row[1 + 2 * j], 0, &row[1 + 2 * j])) return 1;
+                row[2 + 2 * j] &= 0xFFFFu;
+            } else {
+                if (j >= nn) { row[1 + j] = 0; continue; }
+                if (encode_node(h, i, j, row[1 + j], (row[1 + j] >> 16) & 0xFF, &row[1 + j])) return 1;
             }
-            // (any other class id, e.g. 255 for a name without objects such as "Agent": neither flag, matches nothing)
-            row[1 + j] = w;
         }
         row[0] = nn & 0xFFu;
     }
@@ -401,12 +414,14 @@ extern "C" int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n) {
     // node of a walkable static class (Floor, Switch, Block) -- the only statics a carried object can be "at".
     int sensitive = h->P.A > 2;
     for (int i = 0; i < n && !sensitive; ++i) {
-        const uint32_t *row = table + (size_t)i * (1 + MAX_NODES);
+        const uint32_t *row = table + (size_t)i * row_words;
+        auto node = [&](uint32_t j) { return wide ? row[1 + 2 * j] : row[1 + j]; };
+        auto kids = [&](uint32_t j) { return wide ? (row[2 + 2 * j] & 0xFFFFu) : ((row[1 + j] >> 16) & 0xFFu); };
         for (uint32_t j = 0; j < row[0] && !sensitive; ++j) {
-            uint32_t cls = row[1 + j] & 0xFF, children = (row[1 + j] >> 16) & 0xFF;
+            uint32_t cls = node(j) & 0xFF, children = kids(j);
             for (uint32_t c = 0; c < row[0]; ++c) {
                 if (!((children >> c) & 1)) continue;
-                uint32_t ccls = row[1 + c] & 0xFF;
+                uint32_t ccls = node(c) & 0xFF;
                 bool pw = cls == FLOOR || cls == SWITCH || cls == BLOCK, cw = ccls == FLOOR || ccls == SWITCH || ccls == BLOCK;
                 bool pd = cls >= 16 && cls < 32, cd = ccls >= 16 && ccls < 32;
                 if ((pw && cd) || (pd && cw)) sensitive = 1;
@@ -414,6 +429,7 @@ extern "C" int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n) {
         }
     }
     h->P.walk_touches = sensitive;
+    h->P.wide = wide ? 1 : 0;
     return 0;
 }
 
@@ -787,7 +803,7 @@ extern "C" int cz_step(cz_handle h, const int32_t *actions, double *obs, double 
     // Small batches (the single-env facade): the step is pure latency, so the kernel reads the actions from and writes
     // its outputs to one pinned, device-mapped host block -- one launch and one synchronisation, no copy commands.
     const size_t o_act = 0, o_rew = (NA * 4 + 15) & ~(size_t)15, o_term = o_rew + NA * 8, o_trunc = o_term + ((NA + 15) & ~(size_t)15),
-                 o_marks = o_trunc + ((NA + 15) & ~(size_t)15), o_obs = o_marks + (((size_t)h->P.N * 4 + 15) & ~(size_t)15),
+                 o_marks = o_trunc + ((NA + 15) & ~(size_t)15), o_obs = o_marks + (((size_t)h->P.N * 8 + 15) & ~(size_t)15),
                  total = o_obs + ob;
     if (total <= h->zero_copy_bytes) {
         if (!h->h_stage) {
@@ -806,7 +822,7 @@ extern "C" int cz_step(cz_handle h, const int32_t *actions, double *obs, double 
         memcpy(rewards, h->h_stage + o_rew, NA * 8);
         memcpy(term, h->h_stage + o_term, NA);
         memcpy(trunc, h->h_stage + o_trunc, NA);
-        h->last_marks.assign((const uint32_t *)(h->h_stage + o_marks), (const uint32_t *)(h->h_stage + o_marks) + h->P.N);
+        h->last_marks.assign((const uint32_t *)(h->h_stage + o_marks), (const uint32_t *)(h->h_stage + o_marks) + 2 * (size_t)h->P.N);
         return 0;
     }
     // Buffers from cz_host_alloc (or any pinned, device-mapped host memory): the kernel reads the actions from and writes
@@ -817,7 +833,7 @@ extern "C" int cz_step(cz_handle h, const int32_t *actions, double *obs, double 
              *d_trunc = mapped_device_pointer(trunc), *d_obs = obs ? mapped_device_pointer(obs) : nullptr;
         if (d_act && d_rew && d_term && d_trunc && (!obs || d_obs)) {
             if (!h->h_marks) {
-                HIPCHK(h, hipHostMalloc((void **)&h->h_marks, (size_t)h->P.N * 4, hipHostMallocMapped));
+                HIPCHK(h, hipHostMalloc((void **)&h->h_marks, (size_t)h->P.N * 8, hipHostMallocMapped));
                 HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_marks_mapped, h->h_marks, 0));
             }
             h->marks_out_next = h->d_marks_mapped;
@@ -826,14 +842,14 @@ extern "C" int cz_step(cz_handle h, const int32_t *actions, double *obs, double 
                 return 1;
             }
             HIPCHK(h, hipStreamSynchronize(h->stream));
-            h->last_marks.assign(h->h_marks, h->h_marks + h->P.N);
+            h->last_marks.assign(h->h_marks, h->h_marks + 2 * (size_t)h->P.N);
             return 0;
         }
     }
     // Pageable buffers: staged copies.  The small outputs (rewards, flags, marks) live in one device block and come back
     // with one copy command through one pinned block; the observation goes straight into the caller's array.
     const size_t s_rew = 0, s_term = NA * 8, s_trunc = s_term + ((NA + 15) & ~(size_t)15), s_marks = s_trunc + ((NA + 15) & ~(size_t)15),
-                 s_total = s_marks + (size_t)h->P.N * 4;
+                 s_total = s_marks + (size_t)h->P.N * 8;
     if (!h->d_actions) {
         HIPCHK(h, hipMalloc(&h->d_actions, NA * 4));
         HIPCHK(h, hipMalloc(&h->d_small, s_total));
@@ -853,15 +869,15 @@ extern "C" int cz_step(cz_handle h, const int32_t *actions, double *obs, double 
     memcpy(rewards, h->h_small + s_rew, NA * 8);
     memcpy(term, h->h_small + s_term, NA);
     memcpy(trunc, h->h_small + s_trunc, NA);
-    h->last_marks.assign((const uint32_t *)(h->h_small + s_marks), (const uint32_t *)(h->h_small + s_marks) + h->P.N);
+    h->last_marks.assign((const uint32_t *)(h->h_small + s_marks), (const uint32_t *)(h->h_small + s_marks) + 2 * (size_t)h->P.N);
     return 0;
 }
 
 extern "C" int cz_last_marks(cz_handle h, uint32_t *out) {
     if (ready(h)) return 1;
     if (!out) return fail(h, "cz_last_marks: null buffer");
-    if (h->last_marks.size() != (size_t)h->P.N) return fail(h, "cz_last_marks: no cz_step has run on this handle yet");
-    memcpy(out, h->last_marks.data(), (size_t)h->P.N * 4);
+    if (h->last_marks.size() != 2 * (size_t)h->P.N) return fail(h, "cz_last_marks: no cz_step has run on this handle yet");
+    memcpy(out, h->last_marks.data(), (size_t)h->P.N * 8);
     return 0;
 }
 

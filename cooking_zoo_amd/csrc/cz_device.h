@@ -29,7 +29,8 @@
 namespace cz {
 
 constexpr int MAX_AGENTS = 4;
-constexpr int MAX_NODES = 8;
+constexpr int MAX_NODES = 8;            // compact recipe tables: rows of 1 + 8 words, marks 8 bits per recipe
+constexpr int WIDE_NODES = 16;          // wide tables (a graph with more than 8 nodes in the book): rows of 1 + 2 * 16 words
 constexpr int HDR_WORDS = 8;
 constexpr int AGENT_WORD0 = HDR_WORDS;
 constexpr int RET_WORD0 = HDR_WORDS + MAX_AGENTS;          // 4 x f64 running episode returns
@@ -41,7 +42,7 @@ enum : uint32_t { CELL_TYPE = 7, CELL_READY = 8, CELL_TOGGLE = 16, CELL_ACTIVE =
 // dyn0 = x | y<<8 | cls<<16 | flags<<24
 enum : uint32_t { D_ALIVE = 1u << 24, D_CHOPPED = 2u << 24, D_MASHED = 4u << 24, D_FREE = 8u << 24, D_DONE = 6u << 24 };
 enum : uint32_t { COND_NONE = 0, COND_CHOPPED, COND_MASHED, COND_NOT_CHOPPED, COND_NOT_MASHED };
-enum : uint32_t { W_T = 0, W_MARKS, W_LAYOUT, W_STATUS, W_EPISODE, W_RECIPES, W_POOL, W_RES1 };
+enum : uint32_t { W_T = 0, W_MARKS, W_LAYOUT, W_STATUS, W_EPISODE, W_RECIPES, W_POOL, W_MARKS_HI };   // word 7: wide tables only
 enum : uint32_t { ST_DONE = 1, ST_TERM = 2, ST_TRUNC = 4 };
 // observation descriptor (one u32 per feature): (image halfword index * 2) | (axis code * 4) << 16  -- soa.py
 constexpr int LUT_Y0 = 64, LUT_ZERO = 126, LUT_ONE = 127;   // + entries 128..255 = 0.0, the "absent" zone
@@ -73,6 +74,7 @@ struct Params {
     int32_t dyn0_off, dyn1_off;    // word offsets inside a record
     int32_t wt;                    // 1: observation stores are write-through (sc1); chosen per launch by the host
     int32_t walk_touches;          // 1 if carrying an object across cells can change a recipe mark (see cz_load_recipes)
+    int32_t wide;                  // 1: wide recipe tables (up to 16 nodes per graph, marks in record words 1 and 7)
     unsigned long long *stamps;    // diagnostic build only: [N][8] s_memtime stamps (nullptr in the shipped library)
     int32_t stop;                  // diagnostic build only: phase index after which the kernel returns (CZ_STOP), else -1
 };
@@ -178,6 +180,7 @@ struct Env {
     uint32_t cell[CPL];            // per lane: cells lane + 64k
     uint32_t agw;                  // lane a < NA: agent a as x | y<<8 | orientation<<16 | (held slot+1)<<24 (record word 8+a)
     uint32_t t, marks, layout, status, episode, recipes, pool;            // uniform header
+    uint32_t marks_hi;             // wide recipe tables only (marks of recipes 2, 3); 0 otherwise
 };
 
 struct Ctx {                       // wave-uniform geometry + this lane's index
@@ -733,6 +736,67 @@ struct Ops {
             if (any) {
                 marks |= 1u << j;
                 if (j > 0 && cx.lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) locs[j * CPL + q] = here.w[q];
+                }
+            }
+        }
+        return marks;
+    }
+
+    // The same evaluation for WIDE recipe tables (graphs of up to 16 nodes): the node words come from the table in memory
+    // (row: n, then per node  the device node word without its child field, the 16-bit child mask), the result has 16
+    // bits.  A cold path by construction: batches whose book fits the compact tables never come here.
+    static __device__ __forceinline__ uint32_t recipe_marks_wide(const E &e, const Ctx &cx, const uint32_t *__restrict__ row,
+                                                              uint64_t *__restrict__ locs) {
+        const int n = (int)(rfl(row[0]) & 0xFFu);
+        uint32_t marks = 0;
+#pragma nounroll
+        for (int j = n - 1; j >= 0; --j) {
+            const uint32_t w = rfl(row[1 + 2 * j]), children = rfl(row[2 + 2 * j]) & 0xFFFFu;
+            if ((marks & children) != children) continue;                 // all(contains.marked)
+            const uint32_t cval = (w & 0x00FF0000u) | D_ALIVE, acc = (w >> 24) & 0xFu;
+            auto matches = [=](uint32_t a) { return (a & 0x01FF0000u) == cval && ((acc >> ((a >> 25) & 3u)) & 1u) != 0u; };
+            CM allow;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) allow.w[q] = ~0ull;
+            uint32_t ch = children;
+            while (ch) {
+                const int c2 = __ffs((int)ch) - 1;
+                ch &= ch - 1;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    const uint64_t lw = locs[c2 * CPL + q];
+                    allow.w[q] &= ((uint64_t)rfl((uint32_t)(lw >> 32)) << 32) | rfl((uint32_t)lw);
+                }
+            }
+            CM here = CM::zero();
+            if (w & 0x200u) {                                             // a static class: candidates are cells
+                const uint32_t cls = (w >> 10) & 7u;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k)
+                    here.w[k] = ballot((e.cell[k] & CELL_TYPE) == cls && (cx.lane + 64 * k) < cx.C) & allow.w[k];
+            } else if (w & 0x2000u) {                                     // a dynamic class
+                OM m;
+#pragma unroll
+                for (int k = 0; k < OPL; ++k) {
+                    const uint32_t mycell = ((e.d0[k] >> 8) & 0xFFu) * (uint32_t)cx.W + (e.d0[k] & 0xFFu);
+                    uint64_t wsel = allow.w[0];
+#pragma unroll
+                    for (int q = 1; q < CPL; ++q)
+                        if ((mycell >> 6) == (uint32_t)q) wsel = allow.w[q];
+                    m.w[k] = ballot(matches(e.d0[k]) && ((wsel >> (mycell & 63)) & 1));
+                }
+                while (m.any()) {
+                    const int sl = m.first();
+                    m.clear(sl);
+                    const uint32_t o = slot_d0(e, sl);
+                    here.set((int)(((o >> 8) & 0xFFu) * (uint32_t)cx.W + (o & 0xFFu)));
+                }
+            }
+            if (here.any()) {
+                marks |= 1u << j;
+                if (cx.lane == 0) {
 #pragma unroll
                     for (int q = 0; q < CPL; ++q) locs[j * CPL + q] = here.w[q];
                 }

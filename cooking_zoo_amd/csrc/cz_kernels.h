@@ -51,7 +51,7 @@ constexpr int OBS_CHUNK = 2 * OBS_PAIRS;   // descriptor words held per lane
 struct Lds {
     uint16_t img[IMG_HALFWORDS];   // objects 6 hw each | cells 4 hw each | agents 8 hw each | the "absent" halfword
     int32_t sub[MAX_AGENTS][16];   // per observer: what to subtract (x8) for each axis code
-    uint64_t locs[MAX_NODES * 4];  // recipe evaluation scratch: matched-location bit sets per node (CPL <= 4 words)
+    uint64_t locs[WIDE_NODES * 4]; // recipe evaluation scratch: matched-location bit sets per node (CPL <= 4 words)
 };
 
 // Memory access helpers: a wave-uniform base pointer plus a 32-bit unsigned per-lane byte offset, which the backend
@@ -97,6 +97,7 @@ __device__ __forceinline__ void load_env(const Params &P, Env<OPL, CPL, NA> &e, 
     }
     e.t = rdl(h, W_T); e.marks = rdl(h, W_MARKS); e.layout = rdl(h, W_LAYOUT); e.status = rdl(h, W_STATUS);
     e.episode = rdl(h, W_EPISODE); e.recipes = rdl(h, W_RECIPES); e.pool = rdl(h, W_POOL);
+    e.marks_hi = P.wide ? rdl(h, W_MARKS_HI) : 0u;
     e.agw = (lane < (uint32_t)NA) ? aw : 0u;
 }
 
@@ -114,6 +115,7 @@ __device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL, N
         h = wrl(e.episode, W_EPISODE, h);
         h = wrl(e.recipes, W_RECIPES, h);
         h = wrl(e.pool, W_POOL, h);
+        h = wrl(e.marks_hi, W_MARKS_HI, h);
         if (lane < (uint32_t)HDR_WORDS) stg<uint32_t>(rec, lane * 4u, h);
     } else if (lane == 0u) {
         stg<uint32_t>(rec, W_T * 4u, e.t);                          // the step counter is all that changed (the usual case)
@@ -146,12 +148,22 @@ __device__ __forceinline__ uint32_t load_recipe_rows(const Params &P, uint32_t r
     return ldg<uint32_t>(P.recipes, (id * (1u + MAX_NODES) + i) * 4u);
 }
 
+// every recipe of the env from scratch (reset): sets e.marks (and e.marks_hi for wide tables)
 template <int OPL, int CPL, int NA>
-__device__ __forceinline__ uint32_t all_marks(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t rowv, Lds &s) {
-    uint32_t marks = 0;
+__device__ __forceinline__ void all_marks(const Params &P, Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t rowv, Lds &s) {
+    uint32_t lo = 0, hi = 0;
+    if (__builtin_expect(P.wide != 0, 0)) {
 #pragma nounroll
-    for (int r = 0; r < P.R; ++r) marks |= Ops<OPL, CPL, NA, 3>::recipe_marks(e, cx, rowv, 9 * r, s.locs) << (8 * r);
-    return marks;
+        for (int r = 0; r < P.R; ++r) {
+            const uint32_t id = (e.recipes >> (8 * r)) & 0xFFu;
+            const uint32_t m = Ops<OPL, CPL, NA, 3>::recipe_marks_wide(e, cx, P.recipes + (size_t)id * (1 + 2 * WIDE_NODES), s.locs);
+            if (r < 2) lo |= m << (16 * r); else hi |= m << (16 * (r - 2));
+        }
+    } else {
+#pragma nounroll
+        for (int r = 0; r < P.R; ++r) lo |= Ops<OPL, CPL, NA, 3>::recipe_marks(e, cx, rowv, 9 * r, s.locs) << (8 * r);
+    }
+    e.marks = lo; e.marks_hi = hi;
 }
 
 // once per kernel and workgroup: the quotient table (thread `tid` of `nthreads`), followed by a workgroup barrier
@@ -320,7 +332,7 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
             uint32_t recipes = e.recipes, episode = e.episode, pool = e.pool;
             load_env(P, e, cx, late_params(kp_off)->lay_init + (size_t)lay * P.RW);
             e.t = 0; e.layout = lay; e.status = 0; e.episode = episode; e.recipes = recipes; e.pool = pool;
-            e.marks = all_marks(P, e, cx, rowv, lds);
+            all_marks(P, e, cx, rowv, lds);
             if (P.obs) load_desc(P, lay, 0, cx.lane, dsc);
             dt.cells = 1; dt.touched = 1; dt.interacted = 1;          // everything must be written back
         } else {
@@ -344,50 +356,91 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
     uint32_t after = before;
     o.myrew = cx.lane < NA ? P.reward_idle : 0.0;
     if (dt.moved & (uint32_t)P.walk_touches) { dt.touched = 1; dt.kinds = ~0ull; }
-    if (dt.touched) {
-        // Which recipes must be re-evaluated?  Marks are a pure function of object state, and (recipe.py:77-104)
-        //  * an object that matches no node of a recipe (class + state conditions) neither before nor after its change is
-        //    in no node's matched list either way, and nothing else asks where it is: the recipe cannot see it;
-        //  * a mere MOVE leaves every leaf's mark alone (leaves have no location constraint), so it can only matter to a
-        //    node that has children, and such a node is only looked at when all its children are marked: if no node of
-        //    the recipe is in that position now, no mark can change (induction from the leaves up).
-        // Both tests run for all nodes of all recipes at once: lane 9r + 1 + j holds node j of recipe r (rowv).
-        const uint32_t nw = rowv, lane_u = (uint32_t)cx.lane;
-        const uint32_t r_of = (lane_u * 57u) >> 9;                                   // lane / 9
-        const uint32_t seen = (uint32_t)(dt.kinds >> ((nw >> 14) & 0x3Cu)) & ((nw >> 24) & 0xFu);
-        const uint32_t kids = nw & 0xFFu, mb = (before >> (8u * (r_of & 3u))) & 0xFFu;
-        constexpr uint64_t NODE_LANES = 0x1FEull | (0x1FEull << 9) | (0x1FEull << 18) | (0x1FEull << 27);
-        const uint64_t relmask = ballot((nw & 0x2000u) != 0u && seen != 0u) & NODE_LANES;
-        const uint64_t sensmask = ballot(kids != 0u && (mb & kids) == kids) & NODE_LANES;
-        after = 0;
+    bool done = false;
+    if (__builtin_expect(P.wide != 0, 0)) {
+        // Wide recipe tables (a graph with more than 8 nodes in the book): no filters, every recipe of the env is
+        // re-evaluated whenever an object moved or changed; marks are 16 bits per recipe (recipes 0, 1 in `marks`, 2, 3 in
+        // `marks_hi`).  Without a change the marks, hence `done` (false, or the env would not be stepping), stay.
+        if (dt.touched) {
+            uint32_t lo = 0, hi = 0;
 #pragma nounroll
-        for (int r = 0; r < P.R; ++r) {
-            const uint32_t mb_r = (before >> (8 * r)) & 0xFF;
-            const bool visible = ((relmask >> (9 * r + 1)) & 0xFFull) != 0ull;
-            const bool sensitive = dt.statechg != 0u || ((sensmask >> (9 * r + 1)) & 0xFFull) != 0ull;
-            const uint32_t ma = (visible && sensitive) ? O::recipe_marks(e, cx, rowv, 9 * r, lds.locs) : mb_r;
-            after |= ma << (8 * r);
-            if (ma != mb_r) {
-                // goals_completed sums (recipe.py:36-40): open goal slots before / after
-                const uint32_t countmask = (uint32_t)((ballot((nw & 0x100u) != 0u) >> (9 * r + 1)) & 0xFFull);
-                const int goals_before = __popc(~mb_r & countmask), goals_after = __popc(~ma & countmask);
-                const bool completed = ma & 1, completion_before = mb_r & 1;
-                const bool malus = !completed && completion_before, bonus = completed && !completion_before;
-                const KParams kp = late_params(kp_off);
-                double x = 0.0;
-                x += (double)(goals_before - goals_after) * kp->node_reward;
-                x += (bonus ? 1.0 : 0.0) * kp->recipe_reward;
-                x += (malus ? 1.0 : 0.0) * kp->recipe_penalty;
-                x += kp->time_penalty_step;
-                if (cx.lane == r && r < NA) o.myrew = x;                   // recipe r is agent r's (cooking_env.py:255-261)
+            for (int r = 0; r < P.R; ++r) {
+                const uint32_t id = (e.recipes >> (8 * r)) & 0xFFu;
+                const uint32_t *row = P.recipes + (size_t)id * (1 + 2 * WIDE_NODES);
+                const uint32_t mb_r = ((r < 2 ? e.marks : e.marks_hi) >> (16 * (r & 1))) & 0xFFFFu;
+                const uint32_t ma = O::recipe_marks_wide(e, cx, row, lds.locs);
+                if (r < 2) lo |= ma << (16 * r); else hi |= ma << (16 * (r - 2));
+                if (ma != mb_r) {
+                    uint32_t countmask = 0;
+                    const int n = (int)(rfl(row[0]) & 0xFFu);
+#pragma nounroll
+                    for (int j = 0; j < n; ++j) countmask |= ((rfl(row[1 + 2 * j]) >> 8) & 1u) << j;
+                    const int goals_before = __popc(~mb_r & countmask), goals_after = __popc(~ma & countmask);
+                    const bool completed = ma & 1, completion_before = mb_r & 1;
+                    const bool malus = !completed && completion_before, bonus = completed && !completion_before;
+                    const KParams kp = late_params(kp_off);
+                    double x = 0.0;
+                    x += (double)(goals_before - goals_after) * kp->node_reward;
+                    x += (bonus ? 1.0 : 0.0) * kp->recipe_reward;
+                    x += (malus ? 1.0 : 0.0) * kp->recipe_penalty;
+                    x += kp->time_penalty_step;
+                    if (cx.lane == r && r < NA) o.myrew = x;
+                }
+            }
+            o.header = lo != e.marks || hi != e.marks_hi;
+            e.marks = lo; e.marks_hi = hi;
+        }
+        // recipe roots are bit 0 of each 16-bit field
+        const uint32_t rlo = e.marks & (P.R >= 2 ? 0x00010001u : 0x00000001u);
+        const uint32_t rhi = P.R >= 3 ? (e.marks_hi & (P.R >= 4 ? 0x00010001u : 0x00000001u)) : 0u;
+        const int n_roots = __popc(rlo) + __popc(rhi);
+        done = P.end_all ? (n_roots == P.R) : (n_roots != 0);
+    } else {
+        if (dt.touched) {
+            // Which recipes must be re-evaluated?  Marks are a pure function of object state, and (recipe.py:77-104)
+            //  * an object that matches no node of a recipe (class + state conditions) neither before nor after its change is
+            //    in no node's matched list either way, and nothing else asks where it is: the recipe cannot see it;
+            //  * a mere MOVE leaves every leaf's mark alone (leaves have no location constraint), so it can only matter to a
+            //    node that has children, and such a node is only looked at when all its children are marked: if no node of
+            //    the recipe is in that position now, no mark can change (induction from the leaves up).
+            // Both tests run for all nodes of all recipes at once: lane 9r + 1 + j holds node j of recipe r (rowv).
+            const uint32_t nw = rowv, lane_u = (uint32_t)cx.lane;
+            const uint32_t r_of = (lane_u * 57u) >> 9;                                   // lane / 9
+            const uint32_t seen = (uint32_t)(dt.kinds >> ((nw >> 14) & 0x3Cu)) & ((nw >> 24) & 0xFu);
+            const uint32_t kids = nw & 0xFFu, mb = (before >> (8u * (r_of & 3u))) & 0xFFu;
+            constexpr uint64_t NODE_LANES = 0x1FEull | (0x1FEull << 9) | (0x1FEull << 18) | (0x1FEull << 27);
+            const uint64_t relmask = ballot((nw & 0x2000u) != 0u && seen != 0u) & NODE_LANES;
+            const uint64_t sensmask = ballot(kids != 0u && (mb & kids) == kids) & NODE_LANES;
+            after = 0;
+    #pragma nounroll
+            for (int r = 0; r < P.R; ++r) {
+                const uint32_t mb_r = (before >> (8 * r)) & 0xFF;
+                const bool visible = ((relmask >> (9 * r + 1)) & 0xFFull) != 0ull;
+                const bool sensitive = dt.statechg != 0u || ((sensmask >> (9 * r + 1)) & 0xFFull) != 0ull;
+                const uint32_t ma = (visible && sensitive) ? O::recipe_marks(e, cx, rowv, 9 * r, lds.locs) : mb_r;
+                after |= ma << (8 * r);
+                if (ma != mb_r) {
+                    // goals_completed sums (recipe.py:36-40): open goal slots before / after
+                    const uint32_t countmask = (uint32_t)((ballot((nw & 0x100u) != 0u) >> (9 * r + 1)) & 0xFFull);
+                    const int goals_before = __popc(~mb_r & countmask), goals_after = __popc(~ma & countmask);
+                    const bool completed = ma & 1, completion_before = mb_r & 1;
+                    const bool malus = !completed && completion_before, bonus = completed && !completion_before;
+                    const KParams kp = late_params(kp_off);
+                    double x = 0.0;
+                    x += (double)(goals_before - goals_after) * kp->node_reward;
+                    x += (bonus ? 1.0 : 0.0) * kp->recipe_reward;
+                    x += (malus ? 1.0 : 0.0) * kp->recipe_penalty;
+                    x += kp->time_penalty_step;
+                    if (cx.lane == r && r < NA) o.myrew = x;                   // recipe r is agent r's (cooking_env.py:255-261)
+                }
             }
         }
+        e.marks = after;
+        o.header = after != before;
+        // recipe roots are bit 0 of each marks byte
+        const uint32_t roots = after & 0x01010101u & (P.R >= 4 ? 0xFFFFFFFFu : ((1u << (8 * P.R)) - 1u));
+        done = P.end_all ? (__popc(roots) == P.R) : (roots != 0u);
     }
-    e.marks = after;
-    o.header = after != before;
-    // recipe roots are bit 0 of each marks byte
-    const uint32_t roots = after & 0x01010101u & (P.R >= 4 ? 0xFFFFFFFFu : ((1u << (8 * P.R)) - 1u));
-    const bool done = P.end_all ? (__popc(roots) == P.R) : (roots != 0u);
     o.term = done ? 1u : 0u;
     o.trunc = truncated ? 1u : 0u;
     if (done || truncated) {
@@ -496,7 +549,8 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(uint32_t *e_state, co
                 su[SU_EPISODES] += 1; su[SU_LENSUM] += e.t; su[SU_TRUNC] += o.trunc; su[SU_TERM] += o.term;
             }
             if (lane < NA) {
-                su[SU_COMPLETED0 + lane] += (e.marks >> (8 * lane)) & 1u;
+                const uint32_t root = Pt.wide ? (((lane < 2 ? e.marks : e.marks_hi) >> (16 * (lane & 1))) & 1u) : ((e.marks >> (8 * lane)) & 1u);
+                su[SU_COMPLETED0 + lane] += root;
                 sf[SF_SUM0 + lane] += ret;
             }
             ret = 0.0;
@@ -512,7 +566,7 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(uint32_t *e_state, co
         }
         if (!FUSED) {
             uint32_t *const marks_out = kp->marks_out;
-            if (marks_out && lane == 0) marks_out[env] = e.marks;               // infos["recipe_done"] of the host API
+            if (marks_out && lane < 2) marks_out[2 * (size_t)env + lane] = lane == 0 ? e.marks : e.marks_hi;   // infos["recipe_done"] of the host API
         }
         CZ_STAMP(5);
         img_objs |= (dt.touched | dt.moved) != 0;
@@ -549,7 +603,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin,
     e.t = 0; e.layout = lay; e.status = 0; e.episode = old_episode; e.recipes = rfl(recipe_words[i]);
     e.pool = rfl(pool_words[i]);
     uint32_t rowv = load_recipe_rows(P, e.recipes, lane);
-    e.marks = all_marks(P, e, cx, rowv, lds);
+    all_marks(P, e, cx, rowv, lds);
     store_env(P, e, cx, rec, true, true);
     if (lane < MAX_AGENTS) reinterpret_cast<double *>(rec + RET_WORD0)[lane] = 0.0;
     if (obs_out) {

@@ -314,11 +314,12 @@ class CookingEnvironment:
         return out
 
     def _refresh_marks(self):
-        self._set_marks(int(self._vec.get_state()[0, soa.W_MARKS]))
+        rec = self._vec.get_state()[0]
+        self._set_marks(int(rec[soa.W_MARKS]) | (int(rec[soa.W_MARKS_HI]) << 32))
 
     def _set_marks(self, marks):
         for r, g in enumerate(self.recipe_graphs):
-            g.set_marks((marks >> (8 * r)) & 0xFF)
+            g.set_marks(self._vec.marks_of(marks, r))
 
     @property
     def world(self):

@@ -15,7 +15,8 @@ Per-env *record* (array of little-endian u32 words, `record_words(cfg)` long):
   word 5      recipe ids             4 x u8, index into the recipe table, 0xFF = unused
   word 6      layout pool            base | count<<16: the slice of the layout pool this env redraws from on
                                      auto-reset (0 = whole pool); lets one batch mix levels
-  word 7      reserved
+  word 7      marks of recipes 2, 3 when the recipe tables are wide (more than 8 nodes per graph: 16 bits per recipe,
+              recipes 0, 1 in word 1); otherwise 0
   word 8..11  agents[4]              x | y<<8 | orientation<<16 | (held slot+1)<<24   world_objects.py:776-783
   word 12..19 ret[4]                 float64 running return of the episode in flight, per agent slot
                                      (cooking_env.py:265 _cumulative_rewards; device-side statistics only)
@@ -58,7 +59,9 @@ NODE_CLS_STATIC0 = 0          # + static type
 NODE_CLS_DYN0 = 16            # + dynamic class
 NODE_CLS_NONE = 255           # class with no objects (e.g. an unknown name)
 COND_NONE, COND_CHOPPED, COND_MASHED, COND_NOT_CHOPPED, COND_NOT_MASHED = range(5)
-MAX_NODES = 8
+MAX_NODES = 16               # node capacity of a recipe graph (the reference has none, recipe.py:29-34)
+NARROW_NODES = 8             # graphs up to this size use the compact tables: rows of 9 words, marks 8 bits per recipe in
+                             # record word 1; larger ones ("wide"): rows of 33 words, marks 16 bits per recipe in words 1 and 7
 MAX_RECIPES_PER_ENV = 4
 MAX_AGENTS = 4
 
@@ -89,6 +92,7 @@ def ax_self(agent, axis):
 
 HDR_WORDS = 8
 W_T, W_MARKS, W_LAYOUT, W_STATUS, W_EPISODE, W_RECIPES, W_POOL, W_RES1 = range(8)
+W_MARKS_HI = W_RES1          # wide recipe tables only: marks of recipes 2 and 3
 AGENT_WORD0 = HDR_WORDS
 RET_WORD0 = AGENT_WORD0 + 4          # 4 float64 = 8 words
 STATUS_DONE, STATUS_TERM, STATUS_TRUNC = 1, 2, 4

@@ -107,7 +107,10 @@ class CookingVecEnv:
 
         # ---- recipe tables
         self.book, self.book_names = resolve_recipe_tables(recipes)
-        self.recipe_table = np.stack([self.book[n]().flatten() for n in self.book_names])
+        graphs = [self.book[n]() for n in self.book_names]
+        # compact tables while every graph of the book has at most 8 nodes, wide ones (16) otherwise
+        self.recipe_nodes = soa.NARROW_NODES if max(len(g.node_list) for g in graphs) <= soa.NARROW_NODES else soa.MAX_NODES
+        self.recipe_table = np.stack([g.flatten(self.recipe_nodes) for g in graphs])
         if isinstance(recipes, np.ndarray):
             rid = np.asarray(recipes, dtype=np.int64)
             assert rid.shape[0] == self.num_envs
@@ -155,7 +158,7 @@ class CookingVecEnv:
         self._h = h
         self.env_id_base = int(env_id_base)
         assert L.cz_record_words(self._h) == self.dims.RW
-        _native.check(self._h, L.cz_load_recipes(self._h, _ptr(self.recipe_table), len(self.book_names)))
+        _native.check(self._h, L.cz_load_recipes(self._h, _ptr(self.recipe_table), len(self.book_names), self.recipe_nodes))
         self._upload_layouts()
         self._buffers = []
         self.env_level = np.arange(self.num_envs) % len(self.levels)
@@ -275,10 +278,16 @@ class CookingVecEnv:
         return out[0]
 
     def last_marks(self):
-        """Recipe-node marks (uint32 [N], bit 8r+j) after the most recent host-array `step`."""
-        marks = np.empty(self.num_envs, dtype=np.uint32)
-        _native.check(self._h, _native.lib().cz_last_marks(self._h, _ptr(marks)))
-        return marks
+        """Recipe-node marks after the most recent host-array `step`: uint64 [N], bit 8r + j = node j of the env's r-th
+        recipe (compact tables) or bit 16r + j (wide tables, `recipe_nodes == 16`)."""
+        words = np.empty((self.num_envs, 2), dtype=np.uint32)
+        _native.check(self._h, _native.lib().cz_last_marks(self._h, _ptr(words)))
+        return words[:, 0].astype(np.uint64) | (words[:, 1].astype(np.uint64) << np.uint64(32))
+
+    def marks_of(self, marks, r):
+        """the node marks of recipe r inside a marks value (an int): bit j = node j of node_list"""
+        bits = 8 if self.recipe_nodes == soa.NARROW_NODES else 16
+        return (int(marks) >> (bits * r)) & ((1 << bits) - 1)
 
     def observe(self, env_begin=0, env_count=None):
         n = self.num_envs if env_count is None else int(env_count)

@@ -14,7 +14,7 @@
  *
  * Per-env state travels as a flat "record" of cz_record_words() little-endian uint32 words:
  *   word 0 t | 1 recipe-node marks (bit 8r+j) | 2 layout id | 3 status (1 done, 2 terminated, 4 truncated)
- *   | 4 episode | 5 recipe ids (4 x u8) | 6 layout-pool slice (base | count<<16) | 7 reserved | 8..11 agents (x | y<<8 | orientation<<16 | (held slot+1)<<24)
+ *   | 4 episode | 5 recipe ids (4 x u8) | 6 layout-pool slice (base | count<<16) | 7 marks of recipes 2, 3 (wide recipe tables only) | 8..11 agents (x | y<<8 | orientation<<16 | (held slot+1)<<24)
  *   | 12..19 four float64 running episode returns (statistics only) | cells (W*H bytes: type | READY<<3 | TOGGLE<<4 | ACTIVE<<5 | WALK<<6) | dyn0[D] (x | y<<8 | class<<16 | flags<<24;
  *   flags: 1 alive, 2 chopped, 4 mashed, 8 free) | dyn1[D] ((plate slot+1) | seq<<8), padded to 16 words.
  * (normative description: cooking_zoo_amd/soa.py)
@@ -80,11 +80,15 @@ int cz_set_stream(cz_handle h, void *hip_stream);
 
 /* ---- tables ---------------------------------------------------------------------------------------- */
 /* Recipe graphs: replaces RECIPES[name]() / Recipe.node_list (recipe_drawer.py:109-118, recipe.py:29-34).
- * table[n][9]: word 0 = node count (<= 8); then per node (root first, node_list order)
- *   class | condition<<8 | child-mask<<16 | counts-in-goal-sum<<24
- *   class: 0..6 static type, 16..25 dynamic class, 255 none; condition: 0 none, 1 chopped, 2 mashed,
- *   3 not chopped, 4 not mashed. */
-int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n_recipes);
+ * max_nodes = 8 (compact): table[n][9], word 0 = node count (<= 8), then per node (root first, node_list order)
+ *   class | condition<<8 | child-mask<<16 | counts-in-goal-sum<<24; the marks of recipe r are bits 8r.. of record word 1.
+ * max_nodes = 16 (wide, for books with a graph of more than 8 nodes): table[n][33], word 0 = node count (<= 16), then per
+ *   node TWO words: class | condition<<8 | counts<<24, child-mask (16 bits); marks are 16 bits per recipe: recipes 0, 1 in
+ *   record word 1, recipes 2, 3 in word 7.  Wide batches re-evaluate every recipe on every step that changed an object.
+ * class: 0..6 static type, 16..25 dynamic class, 255 none; condition: 0 none, 1 chopped, 2 mashed, 3 not chopped,
+ * 4 not mashed, or 0x10 | accept mask over the object state (chopped | mashed << 1) for several (attr, value) conditions
+ * on one node (recipe.py:96-98 loops over all of them). */
+int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n_recipes, int32_t max_nodes);
 
 /* Layout pool: replaces load_level / parsing (load_level.py:55-71, parsing.py:5-151) results.  Per layout:
  * its initial record (cz_record_words words; t, marks, status ignored) and its observation descriptor
@@ -119,7 +123,8 @@ int cz_step(cz_handle h, const int32_t *actions, double *obs, double *rewards, u
 
 /* Recipe-node marks (record word 1: bit 8r+j = node j of the env's r-th recipe is met, bit 8r = recipe r complete) of
  * every env after the most recent cz_step: what compute_infos reports as `recipe_done` (cooking_env.py:317-331).
- * uint32 [N].  Fails if cz_step has not run on this handle. */
+ * uint32 [N][2]: record words 1 and 7 (the second is 0 unless the recipe tables are wide).  Fails if cz_step has not run
+ * on this handle. */
 int cz_last_marks(cz_handle h, uint32_t *marks);
 
 /* Device-pointer form, asynchronous on the handle's stream (d_obs may be NULL: encode skipped). */

@@ -23,7 +23,7 @@
 #include <string.h>
 
 #define CZO_MAX_AGENTS 4
-#define CZO_MAX_NODES 8
+#define CZO_MAX_NODES 16          /* recipe.py puts no limit on a graph; the flat tables carry up to 16 nodes */
 #define CZO_MAX_RECIPES 4
 #define CZO_MAX_CELLS 1024
 #define CZO_MAX_DYN 250
@@ -46,6 +46,8 @@ typedef struct {
     int32_t auto_reset;           /* 0: done envs freeze; 1: next-step reset from the layout pool */
     int32_t num_layouts;
     int32_t record_words;
+    int32_t recipe_nodes;         /* node capacity of a recipe-table row: 8 (rows of 9 words, marks 8 bits per recipe in
+                                     word 1) or 16 (rows of 33 words, marks 16 bits per recipe in words 1 and 7) */
     double recipe_reward, max_time_penalty, recipe_penalty, recipe_node_reward;
 } czo_config;
 
@@ -577,13 +579,41 @@ static void world_step(World *w, const int *actions)
 /* ------------------------------------------------------------------------------------------ */
 /* recipes: recipe.py:77-104                                                                   */
 
-typedef struct { int n; uint32_t node[CZO_MAX_NODES]; } Recipe;
+typedef struct { int n; uint32_t node[CZO_MAX_NODES]; uint32_t children[CZO_MAX_NODES]; } Recipe;
 
-static void load_recipe(Recipe *r, const uint32_t *table, int id)
+/* narrow rows: n, then per node  class | cond << 8 | child mask << 16 | counts << 24
+ * wide rows:   n, then per node two words:  class | cond << 8 | counts << 24,  child mask (16 bits) */
+static void load_recipe(Recipe *r, const czo_config *cfg, const uint32_t *table, int id)
 {
-    const uint32_t *p = table + (size_t)id * (1 + CZO_MAX_NODES);
-    r->n = (int)p[0];
-    for (int j = 0; j < CZO_MAX_NODES; ++j) r->node[j] = p[1 + j];
+    if (cfg->recipe_nodes > 8) {
+        const uint32_t *p = table + (size_t)id * (1 + 2 * CZO_MAX_NODES);
+        r->n = (int)p[0];
+        for (int j = 0; j < CZO_MAX_NODES; ++j) { r->node[j] = p[1 + 2 * j]; r->children[j] = p[2 + 2 * j] & 0xFFFFu; }
+    } else {
+        const uint32_t *p = table + (size_t)id * (1 + 8);
+        r->n = (int)p[0];
+        for (int j = 0; j < CZO_MAX_NODES; ++j) {
+            r->node[j] = j < 8 ? p[1 + j] : 0;
+            r->children[j] = j < 8 ? (p[1 + j] >> 16) & 255u : 0;
+        }
+    }
+}
+
+/* the marks of recipe r inside the record: 8 bits per recipe in word 1, or 16 bits per recipe in words 1 (recipes 0, 1)
+ * and 7 (recipes 2, 3) */
+static uint32_t get_marks(const czo_config *cfg, const uint32_t *rec, int r)
+{
+    if (cfg->recipe_nodes > 8) return (rec[r < 2 ? W_MARKS : W_RES1] >> (16 * (r & 1))) & 0xFFFFu;
+    return (rec[W_MARKS] >> (8 * r)) & 255u;
+}
+static void set_marks(const czo_config *cfg, uint32_t *rec, int r, uint32_t m)
+{
+    if (cfg->recipe_nodes > 8) {
+        uint32_t *w = &rec[r < 2 ? W_MARKS : W_RES1];
+        *w = (*w & ~(0xFFFFu << (16 * (r & 1)))) | (m << (16 * (r & 1)));
+    } else {
+        rec[W_MARKS] = (rec[W_MARKS] & ~(255u << (8 * r))) | (m << (8 * r));
+    }
 }
 
 /* returns marks bitmask (bit j = node j of node_list marked) */
@@ -595,7 +625,7 @@ static uint32_t update_recipe_state(const World *w, const Recipe *r)
     uint32_t marks = 0;
     for (int j = r->n - 1; j >= 0; --j) {                 /* reversed(node_list) */
         uint32_t nd = r->node[j];
-        int cls = nd & 255, cond = (nd >> 8) & 255, children = (nd >> 16) & 255;
+        int cls = nd & 255, cond = (nd >> 8) & 255, children = (int)r->children[j];
         mn[j] = 0;
         if ((marks & (uint32_t)children) != (uint32_t)children) continue;   /* all(contains.marked) */
         /* iterate world_objects[node.name] */
@@ -715,13 +745,13 @@ typedef struct {
 
 static void recompute_marks(const czo_ctx *cx, World *w, uint32_t *rec)
 {
-    uint32_t marks = 0;
+    rec[W_MARKS] = 0;
+    if (cx->cfg->recipe_nodes > 8) rec[W_RES1] = 0;
     for (int r = 0; r < cx->cfg->num_recipes; ++r) {
         int id = (rec[W_RECIPES] >> (8 * r)) & 255;
-        Recipe R; load_recipe(&R, cx->recipe_table, id);
-        marks |= update_recipe_state(w, &R) << (8 * r);
+        Recipe R; load_recipe(&R, cx->cfg, cx->recipe_table, id);
+        set_marks(cx->cfg, rec, r, update_recipe_state(w, &R));
     }
-    rec[W_MARKS] = marks;
 }
 
 /* layout an env draws for its k-th episode; keyed by the GLOBAL env id so sharding does not change results */
@@ -793,17 +823,16 @@ int czo_step_env(const czo_ctx *cx, int64_t env_local, uint32_t *rec, const int3
 
     /* compute_rewards :290-315 */
     int truncated = (int)rec[W_T] >= cfg->max_steps;            /* compute_truncated :333-350 */
-    uint32_t before = rec[W_MARKS], after = 0;
     int n_completed = 0;
     double rew[CZO_MAX_RECIPES];
     for (int r = 0; r < cfg->num_recipes; ++r) {
         int id = (rec[W_RECIPES] >> (8 * r)) & 255;
-        Recipe R; load_recipe(&R, cx->recipe_table, id);
-        uint32_t mb = (before >> (8 * r)) & 255;
+        Recipe R; load_recipe(&R, cfg, cx->recipe_table, id);
+        uint32_t mb = get_marks(cfg, rec, r);
         int goals_before = open_goals(&R, mb);
         int completion_before = (int)(mb & 1);                  /* root node is node_list[0] */
         uint32_t ma = update_recipe_state(&w, &R);
-        after |= ma << (8 * r);
+        set_marks(cfg, rec, r, ma);
         int goals_after = open_goals(&R, ma);
         int completed = (int)(ma & 1);
         int malus = !completed && completion_before;
@@ -816,7 +845,6 @@ int czo_step_env(const czo_ctx *cx, int64_t env_local, uint32_t *rec, const int3
         rew[r] = x;
         n_completed += completed;
     }
-    rec[W_MARKS] = after;
     int done = cfg->end_condition_all ? (n_completed == cfg->num_recipes) : (n_completed > 0);
     for (int a = 0; a < A; ++a) { rewards[a] = rew[a]; term[a] = (uint8_t)done; trunc[a] = (uint8_t)truncated; }
     if (done || truncated)

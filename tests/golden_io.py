@@ -64,6 +64,14 @@ class GoldenSet:
         self.meta = load_meta_file(self.cfg["meta_file"])
         self.episodes = [Episode(z, i, m) for i, m in enumerate(self.cfg["episodes"])]
         self.scheme = 3 if self.cfg["action_scheme"] == "scheme3" else 1
+        # the recipe book of the set: the default one, or (custom_* sets) the user recipes registered in the reference
+        if "recipe_table" in self.cfg:
+            self.recipe_table = np.asarray(self.cfg["recipe_table"], dtype=np.uint32)
+            self.recipe_ids = [self.cfg["recipe_store"].index(r) for r in self.cfg["recipes"]]
+        else:
+            self.recipe_table = recipe_table()
+            self.recipe_ids = [RECIPE_NAMES.index(r) for r in self.cfg["recipes"]]
+        self.recipe_nodes = int(self.cfg.get("recipe_nodes", soa.NARROW_NODES))
 
 
 def layout_from_episode(ep):

@@ -18,7 +18,7 @@ class Handle:
     """Thin RAII wrapper over the raw C-ABI (tests call exactly what a foreign host would call)."""
 
     def __init__(self, dims, n_envs, *, scheme, max_steps, end_all, num_recipes, reward_scheme=None, auto_reset=0,
-                 env_id_base=0):
+                 env_id_base=0, table=None):
         self.L = _native.lib()
         rs = {"recipe_reward": 20, "max_time_penalty": -5, "recipe_penalty": -40, "recipe_node_reward": 0}
         rs.update(reward_scheme or {})
@@ -32,8 +32,8 @@ class Handle:
         if rc:
             raise RuntimeError(self.L.cz_last_error(None).decode())
         assert self.L.cz_record_words(self.h) == dims.RW
-        tab = recipe_table()
-        self.ck(self.L.cz_load_recipes(self.h, _ptr(tab), tab.shape[0]))
+        tab = recipe_table() if table is None else np.ascontiguousarray(table, dtype=np.uint32)
+        self.ck(self.L.cz_load_recipes(self.h, _ptr(tab), tab.shape[0], 8 if tab.shape[1] == 9 else 16))
 
     def ck(self, rc):
         _native.check(self.h, rc)
@@ -111,8 +111,8 @@ def handle_for_set(gs, **kw):
     dims = eps[0].dims
     h = Handle(dims, len(eps), scheme=gs.scheme, max_steps=gs.cfg["max_steps"],
                end_all=gs.cfg["end_condition_all_dishes"], num_recipes=len(gs.cfg["recipes"]),
-               reward_scheme=gs.cfg.get("reward_scheme"), **kw)
-    rid = [RECIPE_NAMES.index(r) for r in gs.cfg["recipes"]]
+               reward_scheme=gs.cfg.get("reward_scheme"), table=gs.recipe_table, **kw)
+    rid = gs.recipe_ids
     lays = [layout_from_episode(ep) for ep in eps]
     h.load_layouts(np.stack([l.init_record(dims, i, rid) for i, l in enumerate(lays)]),
                    np.stack([l.obs_descriptor(gs.meta, dims) for l in lays]))
@@ -124,11 +124,11 @@ def handle_for_set(gs, **kw):
 def oracle_for_set(gs, lays, **kw):
     eps = gs.episodes
     dims = eps[0].dims
-    rid = [RECIPE_NAMES.index(r) for r in gs.cfg["recipes"]]
+    rid = gs.recipe_ids
     layouts = []
     for i, l in enumerate(lays):
         off, cells = l.static_table()
         layouts.append((l.init_record(dims, i, rid), off, cells))
-    return Oracle(dims, gs.meta, recipe_table(), layouts, scheme=gs.scheme, max_steps=gs.cfg["max_steps"],
+    return Oracle(dims, gs.meta, gs.recipe_table, layouts, scheme=gs.scheme, max_steps=gs.cfg["max_steps"],
                   end_condition_all=gs.cfg["end_condition_all_dishes"], num_recipes=len(gs.cfg["recipes"]),
                   reward_scheme=gs.cfg.get("reward_scheme"), **kw)

@@ -18,7 +18,7 @@ class CzoConfig(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_dyn", C.c_int32), ("num_agents", C.c_int32),
                 ("feat_len", C.c_int32), ("action_scheme", C.c_int32), ("max_steps", C.c_int32),
                 ("end_condition_all", C.c_int32), ("num_recipes", C.c_int32), ("auto_reset", C.c_int32),
-                ("num_layouts", C.c_int32), ("record_words", C.c_int32),
+                ("num_layouts", C.c_int32), ("record_words", C.c_int32), ("recipe_nodes", C.c_int32),
                 ("recipe_reward", C.c_double), ("max_time_penalty", C.c_double), ("recipe_penalty", C.c_double),
                 ("recipe_node_reward", C.c_double)]
 
@@ -69,7 +69,7 @@ class Oracle:
         rs.update(reward_scheme or {})
         self.cfg = CzoConfig(dims.W, dims.H, dims.D, dims.A, dims.F, int(scheme), int(max_steps),
                              int(bool(end_condition_all)), int(num_recipes or dims.A), int(auto_reset), len(layouts),
-                             dims.RW, float(rs["recipe_reward"]), float(rs["max_time_penalty"]),
+                             dims.RW, 16 if np.asarray(recipe_table).shape[1] > 9 else 8, float(rs["recipe_reward"]), float(rs["max_time_penalty"]),
                              float(rs["recipe_penalty"]), float(rs["recipe_node_reward"]))
         self.recipe_table = np.ascontiguousarray(recipe_table, dtype=np.uint32)
         self._keep = []

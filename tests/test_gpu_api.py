@@ -95,7 +95,7 @@ def test_last_marks_matches_state_on_both_host_paths():
         rng = np.random.default_rng(n)
         for t in range(40):
             obs, rew, term, trunc = env.step(rng.integers(0, 5, size=(n, 2)))
-            assert np.array_equal(env.last_marks(), env.get_state()[:, soa.W_MARKS]), (n, t)
+            assert np.array_equal(env.last_marks(), env.get_state()[:, soa.W_MARKS].astype(np.uint64)), (n, t)
         assert np.array_equal(bits(obs), bits(env.observe()))
         env.close()
 

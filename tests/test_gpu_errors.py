@@ -42,7 +42,7 @@ def test_calls_before_tables_and_bad_ranges():
     recs = np.zeros((2, L.cz_record_words(h)), np.uint32)
     assert L.cz_get_state(h, 3, 2, p(recs)) != 0 and b"outside" in L.cz_last_error(h)
     bad_table = np.zeros((1, 9), np.uint32); bad_table[0, 0] = 9
-    assert L.cz_load_recipes(h, p(bad_table), 1) != 0 and b"more than 8 nodes" in L.cz_last_error(h)
+    assert L.cz_load_recipes(h, p(bad_table), 1, 8) != 0 and b"more than 8 nodes" in L.cz_last_error(h)
     with pytest.raises(_native.NativeError):
         _native.check(h, 1)
     assert L.cz_destroy(h) == 0

@@ -44,10 +44,10 @@ def test_layout_record_and_descriptor_match_reference(name):
     gs = GoldenSet(name)
     for ep in gs.episodes:
         lay = layout_from_episode(ep)
-        rid = [RECIPE_NAMES.index(r) for r in gs.cfg["recipes"]]
+        rid = gs.recipe_ids
         rec = lay.init_record(ep.dims, 0, rid)
         ref = ep.states[0].copy()
-        rec[soa.W_MARKS] = ref[soa.W_MARKS]
+        rec[soa.W_MARKS], rec[soa.W_MARKS_HI] = ref[soa.W_MARKS], ref[soa.W_MARKS_HI]
         assert np.array_equal(rec, ref), name
         desc = lay.obs_descriptor(gs.meta, ep.dims)
         for t in range(0, len(ep.states), 7):
@@ -104,7 +104,7 @@ def test_c_abi_exports_every_declared_symbol(repo_root):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in cookingzoo.h but not exported"
     assert declared == {n for n, _, _ in _native.SYMBOLS}, "ctypes binding and header disagree"
-    assert _native.lib().cz_abi_version() == 2
+    assert _native.lib().cz_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

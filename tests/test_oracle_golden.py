@@ -14,7 +14,7 @@ def bits(a):
 
 def make_oracle(gs, ep, **kw):
     off, cells = ep.static_table()
-    return Oracle(ep.dims, gs.meta, recipe_table(), [(ep.states[0], off, cells)], scheme=gs.scheme,
+    return Oracle(ep.dims, gs.meta, gs.recipe_table, [(ep.states[0], off, cells)], scheme=gs.scheme,
                   max_steps=gs.cfg["max_steps"], end_condition_all=gs.cfg["end_condition_all_dishes"],
                   num_recipes=len(gs.cfg["recipes"]), reward_scheme=gs.cfg.get("reward_scheme"), **kw)
 
@@ -35,6 +35,7 @@ def test_oracle_replays_golden(name):
         # reset path: marks re-evaluated from the initial world, obs of the fresh world
         rec2 = ep.states[0].copy()
         rec2[soa.W_MARKS] = 0xDEAD
+        rec2[soa.W_MARKS_HI] = 0xBEEF if gs.recipe_nodes > soa.NARROW_NODES else 0
         obs0 = np.empty((ep.dims.A, ep.dims.F))
         assert orc.reset_env(rec2, 0, obs0) == 0
         assert same_state(ep.dims, rec2, ep.states[0]), f"{name} ep{ei} reset"

@@ -103,17 +103,19 @@ def static_at(world):
     return grid
 
 
-def world_to_record(env, dims, slotmap, layout_id=0, recipe_ids=None):
+def world_to_record(env, dims, slotmap, layout_id=0, recipe_ids=None, recipe_nodes=soa.NARROW_NODES):
     world = env.world
     rec = soa.new_record(dims)
     rec[soa.W_T] = env.t
     marks = 0
+    bits = 8 if recipe_nodes == soa.NARROW_NODES else 16                # compact / wide recipe tables (soa.py)
     for r, g in enumerate(env.recipe_graphs):
-        assert len(g.node_list) <= soa.MAX_NODES
+        assert len(g.node_list) <= recipe_nodes
         for j, node in enumerate(g.node_list):
             if node.marked:
-                marks |= 1 << (8 * r + j)
-    rec[soa.W_MARKS] = marks
+                marks |= 1 << (bits * r + j)
+    rec[soa.W_MARKS] = marks & 0xFFFFFFFF
+    rec[soa.W_MARKS_HI] = marks >> 32
     rec[soa.W_LAYOUT] = layout_id
     rid = [0xFF] * 4
     for i, v in enumerate(recipe_ids or []):
@@ -348,7 +350,7 @@ def level_max_dyn(level_path_or_name):
     return max(n, 1)          # the record always has at least one (possibly unused) slot
 
 
-def capture_episode(cfg, seed, policy_name, max_len=None):
+def capture_episode(cfg, seed, policy_name, max_len=None, recipe_ids=None, recipe_nodes=soa.NARROW_NODES):
     """Returns dict of arrays for one episode (reset + steps until done / max_len)."""
     random.seed(seed)
     np.random.seed(seed)
@@ -365,7 +367,7 @@ def capture_episode(cfg, seed, policy_name, max_len=None):
     D = cfg["max_dyn"]
     dims = soa.Dims(world.width, world.height, D, A, F)
     slotmap = SlotMap(world, D)
-    recipe_ids = [RECIPE_NAMES.index(r) for r in cfg["recipes"]]
+    recipe_ids = [RECIPE_NAMES.index(r) for r in cfg["recipes"]] if recipe_ids is None else list(recipe_ids)
 
     scheme = cfg["action_scheme"]
     pols = []
@@ -384,7 +386,7 @@ def capture_episode(cfg, seed, policy_name, max_len=None):
         else:
             raise ValueError(policy_name)
 
-    states = [world_to_record(env, dims, slotmap, 0, recipe_ids)]
+    states = [world_to_record(env, dims, slotmap, 0, recipe_ids, recipe_nodes)]
     obs = [np.stack([env.observe(a) for a in env.possible_agents])]
     assert obs[0].dtype == np.float64 and obs[0].shape == (A, F)
     actions, rewards, terms, truncs = [], [], [], []
@@ -399,7 +401,7 @@ def capture_episode(cfg, seed, policy_name, max_len=None):
             assert isinstance(env.rewards[a], (float, np.floating)), type(env.rewards[a])
         terms.append([bool(env.terminations[a]) for a in env.possible_agents])
         truncs.append([bool(env.truncations[a]) for a in env.possible_agents])
-        states.append(world_to_record(env, dims, slotmap, 0, recipe_ids))
+        states.append(world_to_record(env, dims, slotmap, 0, recipe_ids, recipe_nodes))
         o = np.stack([env.observe(a) for a in env.possible_agents])
         assert o.dtype == np.float64
         obs.append(o)
@@ -720,6 +722,7 @@ def main():
     sets["layouts_ref"] = lambda: layout_draws(args.out)
     sets["aec_traces"] = lambda: aec_traces(args.out)
     sets["symbolic_traces"] = lambda: symbolic_traces(args.out)
+    sets["custom_recipes"] = lambda: custom_recipes(args.out)          # (registers recipes in the reference: keep last)
     for name, fn in sets.items():
         if args.only and args.only != name:
             continue
@@ -878,6 +881,73 @@ def symbolic_traces(out_dir):
     with gzip.GzipFile(path, "wb", mtime=0) as f:
         f.write(json.dumps(out, sort_keys=False).encode())
     print(f"[golden] symbolic_traces: {len(out)} cases, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def custom_recipes(out_dir):
+    """User recipes through the reference's own registry (recipe_drawer.py:19-35: register_recipe switches the env to
+    RECIPE_STORE / NUM_GOALS, cooking_env.py:100-105): a 10-node graph (two plates under one Deliversquare, seven
+    ingredient leaves -- more than the 8 nodes of the compact tables) and a node with TWO conditions (recipe.py:96-98
+    checks every one): a Banana that is chopped but not mashed.  The fixture carries the flattened tables so that the
+    build's own RecipeNode / register_recipe mirror can be checked against them."""
+    from cooking_zoo.cooking_book import recipe_drawer as rd
+    from cooking_zoo.cooking_book.recipe import Recipe as RefRecipe, RecipeNode as RefNode
+    from cooking_zoo_amd.cooking_book.recipe import _condition_code
+    assert not rd.RECIPE_STORE
+    CH, MA, FRESH_BLEND = ("chop_state", ChopFoodStates.CHOPPED), ("blend_state", BlenderFoodStates.MASHED), ("blend_state", BlenderFoodStates.FRESH)
+    leaf = lambda name, *conds: RefNode(root_type=name, id_num=rd.get_next_id(), name=name, conditions=list(conds))
+    plate = lambda *kids: RefNode(root_type="Plate", id_num=rd.get_next_id(), name="Plate", contains=list(kids))
+    deliver = lambda *kids: RefNode(root_type="Deliversquare", id_num=rd.get_next_id(), name="Deliversquare", contains=list(kids))
+    feast_root = deliver(plate(leaf("Tomato", CH), leaf("Lettuce", CH), leaf("Apple", CH), leaf("Watermelon", CH)),
+                         plate(leaf("Banana", CH, FRESH_BLEND), leaf("Carrot", MA), leaf("Bread", CH)))
+    picky_root = deliver(plate(leaf("Banana", CH, FRESH_BLEND)))
+    snack_root = deliver(plate(leaf("Bread", CH)))
+    roots = {"FruitFeast": feast_root, "PickyBanana": picky_root, "BreadSnack": snack_root}
+    for name, root in roots.items():
+        rd.register_recipe(RefRecipe(root, rd.NUM_GOALS), name)
+    names = list(rd.RECIPE_STORE.keys())
+    # cooking_env.py:7 copies NUM_GOALS at import time (`from ... import NUM_GOALS`), so in the reference user recipes
+    # only work when their nodes were created BEFORE cooking_env was first imported; emulate that order here
+    import cooking_zoo.environment.cooking_env as ref_env_module
+    ref_env_module.NUM_GOALS = rd.NUM_GOALS
+
+    def flatten(g, max_nodes):
+        wide = max_nodes > soa.NARROW_NODES
+        out = [0] * (1 + (2 * soa.MAX_NODES if wide else soa.NARROW_NODES))
+        out[0] = len(g.node_list)
+        index = {id(n): j for j, n in enumerate(g.node_list)}
+        last = {n.id_num: j for j, n in enumerate(g.node_list)}
+        for j, n in enumerate(g.node_list):
+            kids = sum(1 << index[id(c)] for c in n.contains)
+            word = soa.class_node_id(n.name) | (_condition_code(n.conditions, n.name) << 8) | ((1 if last[n.id_num] == j else 0) << 24)
+            if wide:
+                out[1 + 2 * j], out[2 + 2 * j] = word, kids
+            else:
+                out[1 + j] = word | (kids << 16)
+        return out
+    graphs = [rd.RECIPE_STORE[n]() for n in names]
+    assert max(len(g.node_list) for g in graphs) == 10
+    table = [flatten(g, soa.MAX_NODES) for g in graphs]
+    rs = {"recipe_reward": 20, "max_time_penalty": -5, "recipe_penalty": -40, "recipe_node_reward": 1}
+    try:
+        for set_name, agents, recipes, scheme, plan in (
+                ("custom_wide_coop", 2, ["FruitFeast", "PickyBanana"], "scheme3", [(600, "bumper", 300), (601, "uniform", 300), (602, "bumper", 300)]),
+                # (more recipes than agents: the third graph's marks live in record word 7)
+                ("custom_wide_scheme1", 2, ["BreadSnack", "PickyBanana", "FruitFeast"], "scheme1", [(610, "bumper", 300), (611, "bumper", 300), (612, "uniform", 300)])):
+            level = "coop_test" if agents <= 2 else os.path.join(REPO, "cooking_zoo_amd", "utils", "level", "crowded_6x5.json")
+            meta = "example" if agents <= 2 else os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", "crowded_6x5.json")
+            cfg = base_cfg(level, agents, recipes, scheme=scheme, max_steps=300, meta=meta, reward_scheme=rs)
+            eps = []
+            for seed, policy, max_len in plan:
+                ep = capture_episode(cfg, seed, policy, max_len, recipe_ids=[names.index(r) for r in recipes], recipe_nodes=soa.MAX_NODES)
+                ep["seed"], ep["policy"] = seed, policy
+                marks = ep["states"][:, soa.W_MARKS].astype(np.uint64) | (ep["states"][:, soa.W_MARKS_HI].astype(np.uint64) << np.uint64(32))
+                print(f"   {set_name} seed={seed} policy={policy}: {episode_stats(ep)} distinct marks values {len(np.unique(marks))}")
+                eps.append(ep)
+            cfg = dict(cfg, recipe_table=table, recipe_nodes=soa.MAX_NODES, recipe_store=names, num_goals=int(rd.NUM_GOALS))
+            save_set(set_name, cfg, eps, out_dir)
+    finally:
+        rd.RECIPE_STORE.clear()
+        ref_env_module.NUM_GOALS = 0
 
 
 def aec_traces(out_dir):
