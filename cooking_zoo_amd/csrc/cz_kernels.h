@@ -259,7 +259,13 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
         if (cx.lane < 16 * NA) (&s.sub[0][0])[cx.lane] = v;
     }
     __builtin_amdgcn_wave_barrier();             // one wave owns this LDS region: DS ops of a wave execute in order
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, NA * P.F * 8, 0x00020000);   // the env's [A][F] block
+    // One buffer resource per observer whose range is exactly that observer's row (F * 8 bytes): the per-lane offset
+    // (feature index * 8) is range-checked by the hardware, dword by dword (the scalar offset would be part of that check,
+    // so the row's base goes into the resource).  Features past F - whole pairs, or the second half of the last pair when
+    // F is odd - are dropped by the memory pipeline and the store sequence needs no lane masks or branches at all.
+    decltype(__builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0)) rs[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) rs[a] = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)a * (uint32_t)P.F, 0, P.F * 8, 0x00020000);
     const bool wt = P.wt != 0;                                                          // wave-uniform
     const char *lutb = reinterpret_cast<const char *>(lut);
     const char *imgb = reinterpret_cast<const char *>(s.img);
@@ -267,7 +273,7 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
     for (int chunk = 0; chunk * 128 * OBS_PAIRS < P.F; ++chunk) {
         if (chunk > 0) load_desc(P, e.layout, chunk, cx.lane, dsc);
         // branch-free stages so that the LDS reads of all pairs and observers are in flight together
-        // (descriptor words past F are 0: they read image halfword 0 and are never stored)
+        // (descriptor words past F are 0: they read image halfword 0 and their stores are out of range)
         uint32_t b[OBS_CHUNK];
 #pragma unroll
         for (int j = 0; j < OBS_CHUNK; ++j) b[j] = *reinterpret_cast<const uint16_t *>(imgb + (dsc[j] & 0xFFFFu));
@@ -284,24 +290,19 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
                 v[a][i].x = *reinterpret_cast<const double *>(lutb + ((int)b[2 * i] - sb[a][2 * i]));
                 v[a][i].y = *reinterpret_cast<const double *>(lutb + ((int)b[2 * i + 1] - sb[a][2 * i + 1]));
             }
+        const uint32_t f0b = (uint32_t)(chunk * OBS_PAIRS * 128 + 2 * cx.lane) * 8u;      // byte offset of this lane's first pair
+        if (wt) {
 #pragma unroll
-        for (int i = 0; i < OBS_PAIRS; ++i) {
-            const int f = (chunk * OBS_PAIRS + i) * 128 + 2 * cx.lane;
-            if (f + 1 < P.F) {
+            for (int i = 0; i < OBS_PAIRS; ++i)
 #pragma unroll
-                for (int a = 0; a < NA; ++a) {
-                    if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v[a][i]), rs, (uint32_t)f * 8u,
-                                                                    (uint32_t)a * (uint32_t)P.F * 8u, 16);
-                    else stg<double2_t>(out + (size_t)a * (uint32_t)P.F, (uint32_t)f * 8u, v[a][i]);
-                }
-            } else if (f < P.F) {                                  // odd F: the last feature stands alone
+                for (int a = 0; a < NA; ++a)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v[a][i]), rs[a], f0b + (uint32_t)i * 1024u, 0, 16);
+        } else {
 #pragma unroll
-                for (int a = 0; a < NA; ++a) {
-                    if (wt) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, v[a][i].x), rs, (uint32_t)f * 8u,
-                                                                   (uint32_t)a * (uint32_t)P.F * 8u, 16);
-                    else stg<double>(out + (size_t)a * (uint32_t)P.F, (uint32_t)f * 8u, v[a][i].x);
-                }
-            }
+            for (int i = 0; i < OBS_PAIRS; ++i)
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v[a][i]), rs[a], f0b + (uint32_t)i * 1024u, 0, 0);
         }
     }
     // the caller keeps the descriptors of chunk 0 across steps (fused rollout): restore them if later chunks replaced them

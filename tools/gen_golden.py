@@ -718,6 +718,16 @@ def main():
             sets[lname + "_scheme1"] = (lambda n=lname, l=llvl: run_set(
                 n + "_scheme1", base_cfg(l, 2, ["TomatoSalad", "CarrotBanana"], scheme="scheme1", max_steps=100, meta=metal),
                 [(410, "bumper", 100), (411, "uniform", 100)], args.out))
+    # an ODD feature length (example meta with one more Tomato slot: F = 283): the last feature has no partner in the
+    # two-features-per-lane observation stores
+    meta_odd = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", "example_odd.json")
+    if os.path.exists(meta_odd):
+        sets["odd_feature_length"] = lambda: run_set(
+            "odd_feature_length", base_cfg("coop_test", 2, ["TomatoLettuceSalad", "CarrotBanana"], max_steps=120, meta=meta_odd),
+            [(700, "bumper", 120), (701, "uniform", 120)], args.out)
+        sets["odd_feature_length_1agent"] = lambda: run_set(
+            "odd_feature_length_1agent", base_cfg("coop_test", 1, ["TomatoSalad"], scheme="scheme1", max_steps=80, meta=meta_odd),
+            [(702, "bumper", 80)], args.out)
     sets["api_traces"] = lambda: api_traces(args.out)
     sets["layouts_ref"] = lambda: layout_draws(args.out)
     sets["aec_traces"] = lambda: aec_traces(args.out)
