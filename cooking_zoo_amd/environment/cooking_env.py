@@ -347,15 +347,13 @@ class AECCookingEnvironment:
 
     def __init__(self, *args, **kwargs):
         self._core = CookingEnvironment(*args, **kwargs)
-        if self._core._spawning:
-            raise NotImplementedError("agent despawn / respawn is offered through parallel_env only")
         self.possible_agents = self._core.possible_agents[:]
         self.agents = self.possible_agents[:]
         self.observation_spaces, self.action_spaces = self._core.observation_spaces, self._core.action_spaces
         self.agent_selection = None
         self._pending = []
         self._turn = 0
-        self._ended_by_truncation = False
+        self._status_changed = False
         self.rewards, self._cumulative_rewards, self.terminations, self.truncations, self.infos = {}, {}, {}, {}, {}
         self._obs = {}
 
@@ -380,7 +378,7 @@ class AECCookingEnvironment:
         self._turn = 0
         self.agent_selection = self.agents[0]
         self._pending = []
-        self._ended_by_truncation = False
+        self._status_changed = False
         self.rewards = {a: 0 for a in self.agents}
         self._cumulative_rewards = {a: 0 for a in self.agents}
         self.terminations = {a: False for a in self.agents}
@@ -407,10 +405,15 @@ class AECCookingEnvironment:
         if self.agent_selection is None:
             raise RuntimeError("reset() must be called before step()")
         if action is None:
-            # a finished agent is acknowledged with None.  After a truncation nobody is active any more, which empties
-            # the agent list; after a termination the reference changes nothing and neither does this.
-            if self._ended_by_truncation:
-                self.agents = []
+            # a finished agent is acknowledged with None (cooking_env.py:216-224): if somebody's spawn status changed in
+            # the last world step -- a despawn, a respawn, or the time limit (which deactivates everybody) -- the agent
+            # list becomes the active agents and the turn goes to the first of them; after a recipe-completion
+            # termination the reference changes nothing and neither does this.
+            if self._status_changed:
+                self.agents = [a for a in self.possible_agents if a in self._core.agents]
+                self._turn = 0
+                if self.agents:
+                    self.agent_selection = self.agents[0]
             return
         me = self.agent_selection
         if self.terminations[me] or self.truncations[me]:
@@ -421,12 +424,14 @@ class AECCookingEnvironment:
         tail = self.agents[-1]                       # whose cumulative reward the reference clears (see class docstring)
         if me == self.agents[-1]:
             actions, self._pending = self._pending, []
-            obs, rew, term, trunc, infos = self._core.step(dict(zip(self.possible_agents, actions)))
-            self._obs = obs
+            obs, rew, term, trunc, infos = self._core.step(dict(zip(self.agents, actions)))
+            self._obs.update(obs)
             self.rewards, self.terminations, self.truncations, self.infos = rew, term, trunc, infos
-            for a in self.possible_agents:
+            for a in rew:
                 self._cumulative_rewards[a] += rew[a]
-            self._ended_by_truncation = any(trunc.values())
+            # the agents this step reports on: the active ones and whoever was despawned by it (cooking_env.py:267-268)
+            self.agents = [a for a in self.possible_agents if a in rew]
+            self._status_changed = any(self._core._status_changed)
             self._turn = 0                            # a fresh selector: the next round starts with the first agent
             for a in self.agents:
                 if term[a] or trunc[a]:

@@ -982,23 +982,49 @@ def aec_traces(out_dir):
                                                 "recipe_node_reward": 1}),
              actions=[[int(a), int(b)] for a, b in np.random.default_rng(9).integers(0, 8, size=(14, 2))]),
     ]
+    # agent despawn / respawn through the agent iterator: the agent list changes under the caller's feet (a despawned
+    # agent is reported truncated once and must be acknowledged with step(None), cooking_env.py:216-224); actions are
+    # drawn on the fly for whoever is selected and recorded in the calls
+    crowd = os.path.join(REPO, "cooking_zoo_amd", "utils", "level", "crowded_6x5.json")
+    metac = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", "crowded_6x5.json")
+    cases += [
+        dict(seed=41, policy_seed=5, max_calls=420,
+             kwargs=dict(level="coop_test", meta_file="example", num_agents=2, max_steps=400,
+                         recipes=["TomatoLettuceSalad", "CarrotBanana"], obs_spaces=["feature_vector", "feature_vector"],
+                         action_scheme="scheme3", agent_respawn_rate=0.3, grace_period=2, agent_despawn_rate=0.2), actions=None),
+        dict(seed=42, policy_seed=6, max_calls=600,
+             # (max_steps is never reached: the reference raises IndexError when it is while somebody is despawned)
+             kwargs=dict(level=crowd, meta_file=metac, num_agents=4, max_steps=400,
+                         recipes=["TomatoSalad", "TomatoLettuceSalad", "no_recipe", "MashedCarrotBanana"],
+                         obs_spaces=["feature_vector"] * 4, action_scheme="scheme1",
+                         agent_respawn_rate=0.25, grace_period=1, agent_despawn_rate=0.2), actions=None),
+    ]
     out = []
     for case in cases:
         random.seed(case["seed"])
         np.random.seed(case["seed"])
         env = CookingEnvironment(**case["kwargs"])
         env.reset()
+        kw = dict(case["kwargs"])
+        for key in ("level", "meta_file"):                    # build-shipped files are referred to by stem
+            if os.path.isabs(kw[key]):
+                kw[key] = os.path.splitext(os.path.basename(kw[key]))[0]
+        case = dict(case, kwargs=kw)
+        prng = np.random.default_rng(case.get("policy_seed", 0))
+        n_act = int(env.action_space("player_0").n)
         names = list(env.possible_agents)
         cursor = {a: 0 for a in names}
         rec = {"seed": case["seed"], "kwargs": case["kwargs"], "possible_agents": names,
                "after_reset": {"agent_selection": env.agent_selection, "agents": list(env.agents)}, "calls": []}
         dead_calls = 0
-        while env.agents and dead_calls < 3:
+        while env.agents and dead_calls < (3 if case["actions"] is not None else 10 ** 9) and len(rec["calls"]) < case.get("max_calls", 10 ** 9):
             agent = env.agent_selection
             obs, cum, term, trunc, info = env.last()
             if term or trunc:
                 action = None
                 dead_calls += 1
+            elif case["actions"] is None:
+                action = int(prng.integers(n_act))
             else:
                 idx = names.index(agent)
                 if cursor[agent] >= len(case["actions"]):
@@ -1016,9 +1042,10 @@ def aec_traces(out_dir):
                           "terminations": {k: bool(v) for k, v in env.terminations.items()},
                           "truncations": {k: bool(v) for k, v in env.truncations.items()}, "t": int(env.t)}})
         out.append(rec)
-    path = os.path.join(out_dir, "aec_traces.json")
-    with open(path, "w") as f:
-        json.dump(out, f)
+    import gzip
+    path = os.path.join(out_dir, "aec_traces.json.gz")
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(json.dumps(out).encode())
     print(f"[golden] aec_traces: {len(out)} cases, {sum(len(r['calls']) for r in out)} calls, {os.path.getsize(path) / 1024:.0f} KiB")
 
 
