@@ -75,7 +75,8 @@ class Layout:
         them: meta-file class order, list order inside a class, zero padding up to the meta count."""
         d = []
         dw = soa.desc_word
-        zero = dw(soa.IMG_ZERO)
+        img_obj0, img_cell0, img_ag0, img_zero = dims.img_layout()
+        zero = dw(img_zero)
         for name, num in meta.items():
             flen = soa.FEATURE_LEN[name]
             emitted = 0
@@ -83,7 +84,7 @@ class Layout:
                 for c in self.static_lists.get(name, []):
                     if flen == 0:
                         continue
-                    i = soa.IMG_CELL0 + 4 * c
+                    i = img_cell0 + 4 * c
                     d += [dw(i, soa.AX_X), dw(i + 1, soa.AX_Y)]
                     if name in ("Switch", "Block"):
                         d.append(dw(i + 2))                    # switch_active / int(walkable)
@@ -96,7 +97,7 @@ class Layout:
                 base, cap = self.slot_base.get(cls, 0), self.slot_cap.get(cls, 0)
                 # slots beyond the meta count cannot be encoded (the reference would emit an over-long vector)
                 for k in range(min(cap, num)):
-                    i = soa.IMG_OBJ0 + 6 * (base + k)
+                    i = img_obj0 + 6 * (base + k)
                     d += [dw(i, soa.AX_X), dw(i + 1, soa.AX_Y)]
                     if cls != soa.PLATE:
                         d.append(dw(i + 2))                                    # int(not done())
@@ -108,7 +109,7 @@ class Layout:
                     emitted += 1
             elif name == "Agent":
                 for a in range(min(dims.A, num)):
-                    i = soa.IMG_AG0 + 8 * a
+                    i = img_ag0 + 8 * a
                     d += [dw(i, soa.ax_self(a, 0)), dw(i + 1, soa.ax_self(a, 1))]
                     d += [dw(i + 2 + o) for o in range(4)]
                     d.append(dw(i + 6))

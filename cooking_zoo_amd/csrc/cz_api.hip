@@ -167,6 +167,7 @@ struct cz_handle_s {
     void *comm = nullptr;
     int n_ranks = 1, rank = 0;
     int wt_override = -1;          // CZ_WT experiment switch, read once
+    bool huge = false;             // the 256-slot / 1024-cell instance (its own LDS image layout)
     bool graphs_enabled = true;    // CZ_GRAPHS=0: cz_step_device_ring launches everything directly
     int32_t ring_prefix = 0;       // CZ_RING_PREFIX: steps of a cz_step_device_ring call launched directly in front of its first graph
     size_t zero_copy_bytes = (size_t)256 << 10;   // cz_step: batches whose buffers fit use the pinned device-mapped block (CZ_ZERO_COPY_BYTES)
@@ -218,10 +219,10 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     if (cfg->num_recipes < cfg->num_agents || cfg->num_recipes > MAX_AGENTS)
         return fail(nullptr, "cz_create: need num_agents <= num_recipes <= 4 (one recipe per agent, cooking_env.py:329)");
     // (the quotient table holds 2W-1 x-entries from index 0 and 2H-1 y-entries from index 64, below the constants at 126/127)
-    if (cfg->width < 1 || cfg->height < 1 || cfg->width > 32 || cfg->height > 31 || C > 256)
-        return fail(nullptr, "cz_create: grid %dx%d unsupported (W <= 32, H <= 31 and W*H <= 256)", cfg->width, cfg->height);
+    if (cfg->width < 1 || cfg->height < 1 || cfg->width > 32 || cfg->height > 31)
+        return fail(nullptr, "cz_create: grid %dx%d unsupported (W <= 32, H <= 31)", cfg->width, cfg->height);
     static_assert(2 * 32 - 1 <= LUT_Y0 && LUT_Y0 + 2 * 31 - 1 <= LUT_ZERO, "quotient table layout");
-    if (cfg->max_dyn < 1 || cfg->max_dyn > 128) return fail(nullptr, "cz_create: max_dyn must be 1..128");
+    if (cfg->max_dyn < 1 || cfg->max_dyn > 255) return fail(nullptr, "cz_create: max_dyn must be 1..255 (slot + 1 is an 8-bit field)");
     if (cfg->action_scheme != 1 && cfg->action_scheme != 3)
         return fail(nullptr, "cz_create: action_scheme must be 1 or 3 (scheme2 is unusable in the reference)");
     if (cfg->max_steps < 1 || cfg->feat_len < 1) return fail(nullptr, "cz_create: max_steps and feat_len must be positive");
@@ -264,7 +265,8 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     if (const char *s = getenv("CZ_RING_PREFIX")) h->ring_prefix = atoi(s) < 0 ? 0 : (atoi(s) > 16 ? 16 : atoi(s));
     if (const char *s = getenv("CZ_ZERO_COPY_BYTES")) h->zero_copy_bytes = (size_t)atoll(s);
     if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // honoured by the diagnostic build only
-    h->kl = (P.D <= 64 && C <= 64) ? launchers_small() : launchers_large();
+    h->kl = (P.D <= 64 && C <= 64) ? launchers_small() : (P.D <= 128 && C <= 256) ? launchers_large() : launchers_huge();
+    h->huge = P.D > 128 || C > 256;
     {   // the reward of a step on which no recipe node changed: cooking_env.py:304-307 with zero deltas, same op order
         double x = 0.0;
         x += (double)0 * P.node_reward;
@@ -440,10 +442,12 @@ extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const 
         uint32_t off = obs_desc[i] & 0xFFFFu, code4 = obs_desc[i] >> 16;
         uint32_t hw = off >> 1, code = code4 >> 2;
         bool ok = !(off & 1u) && !(code4 & 3u) && (code <= 2 || (code >= 4 && code < 4 + 2 * (uint32_t)h->P.A));
-        if (hw < (uint32_t)IMG_CELL0) ok = ok && (int)(hw / 6) < h->P.D;
-        else if (hw < (uint32_t)IMG_AG0) ok = ok && (int)((hw - IMG_CELL0) / 4) < h->P.W * h->P.H;
-        else if (hw < (uint32_t)IMG_ZERO) ok = ok && (int)((hw - IMG_AG0) / 8) < h->P.A && ((hw - IMG_AG0) & 7u) < 7u;
-        else ok = ok && hw == (uint32_t)IMG_ZERO;
+        const uint32_t cell0 = h->huge ? Img<16>::CELL0 : Img<1>::CELL0, ag0 = h->huge ? Img<16>::AG0 : Img<1>::AG0;
+        const uint32_t zero = h->huge ? Img<16>::ZERO : Img<1>::ZERO;
+        if (hw < cell0) ok = ok && (int)(hw / 6) < h->P.D;
+        else if (hw < ag0) ok = ok && (int)((hw - cell0) / 4) < h->P.W * h->P.H;
+        else if (hw < zero) ok = ok && (int)((hw - ag0) / 8) < h->P.A && ((hw - ag0) & 7u) < 7u;
+        else ok = ok && hw == zero;
         if (!ok) return fail(h, "cz_load_layouts: bad observation descriptor %#x at %zu", obs_desc[i], i);
     }
     HIPCHK(h, hipSetDevice(h->cfg.device_id));

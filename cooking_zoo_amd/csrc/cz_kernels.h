@@ -37,21 +37,30 @@ __device__ __forceinline__ KParams late_params(unsigned offset) {
 #define CZ_LATE_STEP() late_params((unsigned)offsetof(StepArgsMirror, p))
 
 // LDS image of one env (halfwords, cooking_zoo_amd/soa.py IMG_*): every halfword is a BYTE offset into `lut`
-constexpr int IMG_OBJ0 = 0, IMG_CELL0 = 768, IMG_AG0 = 1792, IMG_ZERO = 1824, IMG_HALFWORDS = 1832;
+// Two layouts: up to 128 slots / 256 cells (CPL <= 4), and the "huge" one for up to 256 slots / 1024 cells (CPL = 16).
+template <int CPL>
+struct Img {
+    static constexpr bool HUGE = CPL > 4;
+    static constexpr int OBJ0 = 0, CELL0 = HUGE ? 1536 : 768, AG0 = CELL0 + (HUGE ? 4096 : 1024), ZERO = AG0 + 32, HALFWORDS = ZERO + 8;
+};
 constexpr int LUT_ABSENT = 255, LUT_SIZE = 256;
 #ifndef CZ_ENVS_PER_WG
 #define CZ_ENVS_PER_WG 8
 #endif
 constexpr int ENVS_PER_WG = CZ_ENVS_PER_WG;   // one wavefront per env, this many per workgroup (no cross-wave communication)
+// the huge instance keeps 13.6 KB of LDS per env: four of them (the minimum that still stages the 256-entry table with one
+// entry per thread) fit the 64 KB a workgroup may declare
+template <int CPL> constexpr int envs_per_wg() { return CPL > 4 ? 4 : ENVS_PER_WG; }
 constexpr int OBS_PAIRS = 3;       // feature pairs per lane and chunk: 3 x 128 = 384 features per chunk
 constexpr int OBS_CHUNK = 2 * OBS_PAIRS;   // descriptor words held per lane
 
 // (the quotient table `lut` itself is shared by the waves of a workgroup: [0..2W-2] (i-(W-1))/W | [64..64+2H-2] (i-(H-1))/H |
 // [126] 0.0 | [127] 1.0 | [128..255] 0.0)
+template <int CPL>
 struct Lds {
-    uint16_t img[IMG_HALFWORDS];   // objects 6 hw each | cells 4 hw each | agents 8 hw each | the "absent" halfword
-    int32_t sub[MAX_AGENTS][16];   // per observer: what to subtract (x8) for each axis code
-    uint64_t locs[WIDE_NODES * 4]; // recipe evaluation scratch: matched-location bit sets per node (CPL <= 4 words)
+    uint16_t img[Img<CPL>::HALFWORDS];   // objects 6 hw each | cells 4 hw each | agents 8 hw each | the "absent" halfword
+    int32_t sub[MAX_AGENTS][16];         // per observer: what to subtract (x8) for each axis code
+    uint64_t locs[WIDE_NODES * CPL];     // recipe evaluation scratch: matched-location bit sets per node (CPL words each)
 };
 
 // Memory access helpers: a wave-uniform base pointer plus a 32-bit unsigned per-lane byte offset, which the backend
@@ -152,7 +161,7 @@ __device__ __forceinline__ uint32_t load_recipe_rows(const Params &P, uint32_t r
 
 // every recipe of the env from scratch (reset): sets e.marks (and e.marks_hi for wide tables)
 template <int OPL, int CPL, int NA>
-__device__ __forceinline__ void all_marks(const Params &P, Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t rowv, Lds &s) {
+__device__ __forceinline__ void all_marks(const Params &P, Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t rowv, Lds<CPL> &s) {
     uint32_t lo = 0, hi = 0;
     if (__builtin_expect(P.wide != 0, 0)) {
 #pragma nounroll
@@ -175,9 +184,9 @@ __device__ __forceinline__ void init_lut(const Params &P, double *lut, int tid, 
 
 // once per kernel and env: the constant part of the image (cell coordinates)
 template <int CPL>
-__device__ __forceinline__ void init_lds(const Params &P, const Ctx &cx, Lds &s) {
+__device__ __forceinline__ void init_lds(const Params &P, const Ctx &cx, Lds<CPL> &s) {
     const int lane = cx.lane;
-    if (lane == 0) s.img[IMG_ZERO] = (uint16_t)(LUT_ABSENT * 8);
+    if (lane == 0) s.img[Img<CPL>::ZERO] = (uint16_t)(LUT_ABSENT * 8);
     uint32_t *img32 = reinterpret_cast<uint32_t *>(s.img);
     const uint32_t c01 = (uint32_t)((P.W - 1) * 8) | ((uint32_t)((LUT_Y0 + P.H - 1) * 8) << 16);
 #pragma unroll
@@ -185,7 +194,7 @@ __device__ __forceinline__ void init_lds(const Params &P, const Ctx &cx, Lds &s)
         uint32_t c = (uint32_t)(lane + 64 * k);
         uint32_t y = __umul24(c, P.inv_w) >> 16;             // exact for c < 1024 (checked on the host); full-rate 24-bit multiplies
         uint32_t x = c - __umul24(y, (uint32_t)P.W);
-        img32[(IMG_CELL0 >> 1) + 2 * c] = ((x << 3) | (y << 19)) + c01;
+        img32[(Img<CPL>::CELL0 >> 1) + 2 * c] = ((x << 3) | (y << 19)) + c01;
     }
 }
 
@@ -210,7 +219,7 @@ __device__ __forceinline__ void load_desc(const Params &P, uint32_t layout, int 
 // launch boundary is amortised over T steps, and large batches, whose stores drain while other waves still compute,
 // keep plain stores (policy in cz_api.hip launch_step).
 template <int OPL, int CPL, int NA>
-__device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, Lds &s,
+__device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, Lds<CPL> &s,
                                         const double *lut, uint32_t (&dsc)[OBS_CHUNK], double *__restrict__ out /* [A][F] of this env */,
                                         bool objs_changed = true, bool cells_changed = true) {
     uint32_t *img32 = reinterpret_cast<uint32_t *>(s.img);
@@ -229,23 +238,23 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
         uint32_t q2 = ((uint32_t)(LUT_ZERO * 8) + (ma << 3)) | ((uint32_t)(LUT_ONE * 8) << 16);
         q0 = alive ? q0 : dead; q1 = alive ? q1 : dead; q2 = alive ? q2 : dead;
         const int slot = cx.lane + 64 * k;
-        img32[(IMG_OBJ0 >> 1) + 3 * slot] = q0;
-        img32[(IMG_OBJ0 >> 1) + 3 * slot + 1] = q1;
-        img32[(IMG_OBJ0 >> 1) + 3 * slot + 2] = q2;
+        img32[(Img<CPL>::OBJ0 >> 1) + 3 * slot] = q0;
+        img32[(Img<CPL>::OBJ0 >> 1) + 3 * slot + 1] = q1;
+        img32[(Img<CPL>::OBJ0 >> 1) + 3 * slot + 2] = q2;
     }
     // ---- cells: the mutable flag (switch_active / block walkable) + the constant 1
     if (cells_changed)
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const uint32_t fa = ((e.cell[k] >> 5) | (e.cell[k] >> 6)) & 1u;
-        img32[(IMG_CELL0 >> 1) + 2 * (cx.lane + 64 * k) + 1] = ((uint32_t)(LUT_ZERO * 8) + (fa << 3)) | ((uint32_t)(LUT_ONE * 8) << 16);
+        img32[(Img<CPL>::CELL0 >> 1) + 2 * (cx.lane + 64 * k) + 1] = ((uint32_t)(LUT_ZERO * 8) + (fa << 3)) | ((uint32_t)(LUT_ONE * 8) << 16);
     }
     // ---- agents: 4 dwords each (lane a builds agent a's), and the per-observer subtrahend table
     {
         const uint32_t A = e.agw;
         const uint32_t t = 1u << ((A >> 16) & 0xFFu);
         if (cx.lane < NA) {
-            uint32_t *ag = img32 + (IMG_AG0 >> 1) + 4 * cx.lane;
+            uint32_t *ag = img32 + (Img<CPL>::AG0 >> 1) + 4 * cx.lane;
             ag[0] = (((A & 0xFFu) << 3) | ((A & 0xFF00u) << 11)) + c01;
             ag[1] = f0 + (((t >> 1) & 1u) << 3) + (((t >> 2) & 1u) << 19);
             ag[2] = f0 + (((t >> 3) & 1u) << 3) + (((t >> 4) & 1u) << 19);
@@ -320,7 +329,7 @@ struct StepOut {
 // One accumulated_step (cooking_env.py:243-269) of one env held in registers.
 template <int OPL, int CPL, int NA, int SCHEME>
 __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t acts,
-                                         int64_t env_global, uint32_t &rowv, Lds &lds, uint32_t (&dsc)[OBS_CHUNK], Dirty &dt, StepOut &o) {
+                                         int64_t env_global, uint32_t &rowv, Lds<CPL> &lds, uint32_t (&dsc)[OBS_CHUNK], Dirty &dt, StepOut &o) {
     using O = Ops<OPL, CPL, NA, SCHEME>;
     o.myrew = 0.0;
     o.term = 0; o.trunc = 0; o.stepped = false; o.finished = false; o.header = false;
@@ -467,25 +476,26 @@ __host__ __device__ inline Early early_of(const Params &P) {
 }
 
 template <int OPL, int CPL, int NA, int SCHEME, bool FUSED>
-__global__ __launch_bounds__(64 * ENVS_PER_WG) void k_step(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
+__global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
                                                           int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
                                                           int32_t e_dyn1, const Params P0) {
     Params P = P0;
     P.state = e_state; P.actions = e_actions; P.lut = e_lut; P.N = e_N; P.RW = e_RW; P.W = e_W; P.H = e_H; P.D = e_D;
     P.dyn0_off = e_dyn0; P.dyn1_off = e_dyn1;
-    __shared__ Lds lds_all[ENVS_PER_WG];
+    constexpr int EPW = envs_per_wg<CPL>();
+    __shared__ Lds<CPL> lds_all[EPW];
     __shared__ double lut[LUT_SIZE];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = (int)rfl(threadIdx.x >> 6);
     // (the last workgroup may be partial: its spare waves shadow the last env up to the barrier, then leave)
-    const int env_raw = (int)blockIdx.x * ENVS_PER_WG + wave;
+    const int env_raw = (int)blockIdx.x * EPW + wave;
     const int env = min(env_raw, P.N - 1);
-    static_assert(64 * ENVS_PER_WG >= LUT_SIZE, "one table entry per thread");
+    static_assert(64 * EPW >= LUT_SIZE, "one table entry per thread");
     // the quotient table is shared by the workgroup: its load joins the other loads of the prologue (no branch here:
     // a branch would split the kernel-argument fetch into several dependent round trips)
     double lutv = ldg<double>(P.lut, min(threadIdx.x, 127u) * 8u);
     lutv = threadIdx.x < 128u ? lutv : 0.0;
-    Lds &lds = lds_all[wave];
+    Lds<CPL> &lds = lds_all[wave];
     Ctx cx{P.W, P.H, P.D, P.W * P.H, lane};
     CZ_STAMP(0);
     uint32_t *rec = P.state + (size_t)env * P.RW;
@@ -588,7 +598,7 @@ template <int OPL, int CPL, int NA>
 __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin, const int32_t *__restrict__ layout_ids,
                                               const uint32_t *__restrict__ recipe_words, const uint32_t *__restrict__ pool_words,
                                               double *obs_out) {
-    __shared__ Lds lds;
+    __shared__ Lds<CPL> lds;
     __shared__ double lut[LUT_SIZE];
     init_lut(P, lut, (int)threadIdx.x, 64);
     const int i = blockIdx.x;
@@ -617,7 +627,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin,
 // observe() only (after cz_set_state)
 template <int OPL, int CPL, int NA>
 __global__ __launch_bounds__(64) void k_observe(const Params P, int64_t env_begin, double *obs_out) {
-    __shared__ Lds lds;
+    __shared__ Lds<CPL> lds;
     __shared__ double lut[LUT_SIZE];
     init_lut(P, lut, (int)threadIdx.x, 64);
     const int i = blockIdx.x;
@@ -642,7 +652,8 @@ template <int OPL, int CPL>
 struct Inst {
     template <int NA>
     static hipError_t step_na(const Params &P, hipStream_t st) {
-        const dim3 grid((unsigned)((P.N + ENVS_PER_WG - 1) / ENVS_PER_WG)), block(64 * ENVS_PER_WG);
+        constexpr int EPW = envs_per_wg<CPL>();
+        const dim3 grid((unsigned)((P.N + EPW - 1) / EPW)), block(64 * EPW);
         const Early E = early_of(P);
 #define CZ_LAUNCH_STEP(S, F) \
     hipLaunchKernelGGL((k_step<OPL, CPL, NA, S, F>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, P)
@@ -687,5 +698,6 @@ struct Inst {
 
 Launchers launchers_small();   // D <= 64 slots, W*H <= 64 cells
 Launchers launchers_large();   // D <= 128 slots, W*H <= 256 cells
+Launchers launchers_huge();    // D <= 255 slots, W*H <= 1024 cells
 
 }  // namespace cz

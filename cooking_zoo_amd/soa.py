@@ -77,6 +77,10 @@ MAX_AGENTS = 4
 # A feature value for observer a is  lut[image[hw] - sub[a][code]]  with the axis code choosing what is subtracted:
 #   0 nothing, 1 ax, 2 ay, 4+2j / 5+2j: ax / ay unless a == j (an agent's own position is absolute, cooking_env.py:366-368)
 IMG_OBJ0, IMG_CELL0, IMG_AG0, IMG_ZERO, IMG_HALFWORDS = 0, 768, 1792, 1824, 1826
+# Batches beyond 128 slots or 256 cells run on the "huge" kernel instance (up to 255 slots, 32 x 31 cells), whose image
+# has room for 256 slots and 1024 cells (cz_kernels.h Img<16>):
+HUGE_IMG_OBJ0, HUGE_IMG_CELL0, HUGE_IMG_AG0, HUGE_IMG_ZERO = 0, 1536, 5632, 5664
+MAX_DYN, MAX_W, MAX_H = 255, 32, 31          # (slot + 1) is an 8-bit field; the quotient table holds 2W-1 <= 63, 2H-1 <= 61 entries
 AX_NONE, AX_X, AX_Y = 0, 1, 2
 LUT_Y0, LUT_ZERO, LUT_ONE, LUT_ABSENT, LUT_SIZE = 64, 126, 127, 255, 256
 
@@ -121,6 +125,16 @@ class Dims:
 
     def as_tuple(self):
         return (self.W, self.H, self.D, self.A, self.F)
+
+    @property
+    def huge(self):
+        return self.D > 128 or self.C > 256
+
+    def img_layout(self):
+        """(OBJ0, CELL0, AG0, ZERO) halfword bases of the LDS image this batch's kernel instance keeps"""
+        if self.huge:
+            return HUGE_IMG_OBJ0, HUGE_IMG_CELL0, HUGE_IMG_AG0, HUGE_IMG_ZERO
+        return IMG_OBJ0, IMG_CELL0, IMG_AG0, IMG_ZERO
 
 
 def pack_agent(x, y, orient, holding_slot):

@@ -26,7 +26,7 @@
 #define CZO_MAX_NODES 16          /* recipe.py puts no limit on a graph; the flat tables carry up to 16 nodes */
 #define CZO_MAX_RECIPES 4
 #define CZO_MAX_CELLS 1024
-#define CZO_MAX_DYN 250
+#define CZO_MAX_DYN 255
 #define CZO_PLATE_MAX 64
 
 enum { FLOOR, COUNTER, DELIVERSQUARE, SWITCH, BLOCK, CUTBOARD, BLENDER };

@@ -63,21 +63,22 @@ def eval_descriptor(desc, d, rec):
     for i in range(2 * d.H - 1):
         lut[soa.LUT_Y0 + i] = (i - (d.H - 1)) / d.H
     lut[soa.LUT_ONE] = 1.0
-    img = np.full(soa.IMG_HALFWORDS, soa.LUT_ABSENT, dtype=np.int64)
+    obj0, cell0, ag0, zero = d.img_layout()
+    img = np.full(zero + 2, soa.LUT_ABSENT, dtype=np.int64)
     cells = soa.record_cells(d, rec)
     ag = [soa.unpack_agent(rec[soa.AGENT_WORD0 + a]) for a in range(d.A)]
     for s_ in range(d.D):
         x, y, c, fl = soa.unpack_dyn0(rec[d.dyn0_word0 + s_])
         if fl & soa.DYN_ALIVE:
             ch, ma = bool(fl & soa.DYN_CHOPPED), bool(fl & soa.DYN_MASHED)
-            img[soa.IMG_OBJ0 + 6 * s_:soa.IMG_OBJ0 + 6 * s_ + 6] = [x + d.W - 1, y + 64 + d.H - 1, 126 + (not (ch or ma)),
+            img[obj0 + 6 * s_:obj0 + 6 * s_ + 6] = [x + d.W - 1, y + 64 + d.H - 1, 126 + (not (ch or ma)),
                                                                   126 + ch, 126 + ma, 127]
     for c in range(d.C):
         f = bool(cells[c] & (soa.CELL_ACTIVE | soa.CELL_WALK))
-        img[soa.IMG_CELL0 + 4 * c:soa.IMG_CELL0 + 4 * c + 4] = [c % d.W + d.W - 1, c // d.W + 64 + d.H - 1, 126 + f, 127]
+        img[cell0 + 4 * c:cell0 + 4 * c + 4] = [c % d.W + d.W - 1, c // d.W + 64 + d.H - 1, 126 + f, 127]
     for a in range(d.A):
         x, y, o, _ = ag[a]
-        img[soa.IMG_AG0 + 8 * a:soa.IMG_AG0 + 8 * a + 7] = [x + d.W - 1, y + 64 + d.H - 1] + [126 + (o == k) for k in (1, 2, 3, 4)] + [127]
+        img[ag0 + 8 * a:ag0 + 8 * a + 7] = [x + d.W - 1, y + 64 + d.H - 1] + [126 + (o == k) for k in (1, 2, 3, 4)] + [127]
     out = np.zeros((d.A, d.F))
     for f, w in enumerate(desc):
         w = int(w)

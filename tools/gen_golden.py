@@ -718,6 +718,31 @@ def main():
             sets[lname + "_scheme1"] = (lambda n=lname, l=llvl: run_set(
                 n + "_scheme1", base_cfg(l, 2, ["TomatoSalad", "CarrotBanana"], scheme="scheme1", max_steps=100, meta=metal),
                 [(410, "bumper", 100), (411, "uniform", 100)], args.out))
+    # beyond 128 slots / 256 cells: the third kernel instance (tools/make_levels.py huge_levels)
+    lvl = lambda n: os.path.join(REPO, "cooking_zoo_amd", "utils", "level", n + ".json")
+    mta = lambda n: os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", n + ".json")
+    if os.path.exists(lvl("huge_32x31")):
+        sets["huge_32x31_4agents"] = lambda: run_set(
+            "huge_32x31_4agents",
+            base_cfg(lvl("huge_32x31"), 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"], max_steps=100,
+                     meta=mta("huge_32x31")),
+            [(800, "bumper", 100), (801, "uniform", 100), (802, "mixed", 100)], args.out)
+        sets["huge_32x31_scheme1"] = lambda: run_set(
+            "huge_32x31_scheme1",
+            base_cfg(lvl("huge_32x31"), 2, ["TomatoLettuceOnionSalad", "MashedCarrotBanana"], scheme="scheme1", max_steps=60,
+                     meta=mta("huge_32x31")),
+            [(810, "bumper", 60), (811, "uniform", 60)], args.out)
+    if os.path.exists(lvl("huge_20x20")):
+        sets["huge_20x20"] = lambda: run_set(
+            "huge_20x20",
+            base_cfg(lvl("huge_20x20"), 3, ["TomatoLettuceSalad", "MashedCarrotBanana", "TomatoSalad"], max_steps=150, meta=mta("huge_20x20")),
+            [(820, "bumper", 150), (821, "uniform", 150), (822, "mixed", 150)], args.out)
+    if os.path.exists(lvl("huge_objs_16x16")):
+        sets["huge_objs_16x16"] = lambda: run_set(
+            "huge_objs_16x16",
+            base_cfg(lvl("huge_objs_16x16"), 3, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon"], max_steps=120,
+                     meta=mta("huge_objs_16x16")),
+            [(830, "bumper", 120), (831, "uniform", 120), (832, "mixed", 120)], args.out)
     # an ODD feature length (example meta with one more Tomato slot: F = 283): the last feature has no partner in the
     # two-features-per-lane observation stores
     meta_odd = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", "example_odd.json")

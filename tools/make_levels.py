@@ -162,6 +162,80 @@ def limit_levels():
     return out, meta
 
 
+def huge_levels():
+    """beyond 128 slots / 256 cells (the third kernel instance):
+    * huge_32x31: the largest grid there is (992 cells) with every one of the 255 slots in use, 4 agents,
+    * huge_20x20: 400 cells with few objects (only the cell count is over the old cap),
+    * huge_objs_16x16: 256 cells with 190 slots (only the object count is over the old cap)"""
+    out = {}
+    one = lambda name, x, y: {name: {"COUNT": 1, "X_POSITION": [x], "Y_POSITION": [y]}}
+    foods = ["Tomato", "Onion", "Lettuce", "Carrot", "Banana", "Apple", "Watermelon", "Cucumber"]
+
+    def grid(W, H, block_rows, x0, x1):
+        rows = []
+        for y in range(H):
+            rows.append("".join("-" if (x in (0, W - 1) or y in (0, H - 1) or (x0 <= x <= x1 and y in block_rows)) else " "
+                                for x in range(W)))
+        return rows
+
+    # ---- 32 x 31, all 255 slots
+    W, H = 32, 31
+    rows = grid(W, H, (3, 4, 8, 9, 13, 14, 18, 19, 23, 24, 27), 2, 29)
+    statics = [one("Cutboard", x, y) for x, y in [(2, 3), (29, 4), (10, 13), (20, 14), (2, 23), (29, 24)]]
+    statics += [one("Blender", 0, 10), one("Blender", 31, 20), one("Blender", 15, 27)]
+    statics += [{"Deliversquare": {"COUNT": 3, "X_POSITION": [5, 16, 26], "Y_POSITION": [0]}}, one("Deliversquare", 16, 30)]
+    # (one Switch only: a second one crashes the reference, SURVEY A.8 -- Switch has no switch_state)
+    statics += [one("Switch", 1, 6), one("Block", 1, 11), one("Block", 30, 16)]
+    counts = [("Plate", 25)] + [(n, 28) for n in foods] + [("Bread", 3)]
+    assert sum(c for _, c in counts) + 3 == 255
+    dyn = [{n: {"COUNT": c, "X_POSITION": list(range(W)), "Y_POSITION": list(range(H))}} for n, c in counts]
+    agents = [{"MAX_COUNT": 1, "X_POSITION": [1], "Y_POSITION": [1]},
+              {"MAX_COUNT": 1, "X_POSITION": [30], "Y_POSITION": [29]},
+              {"MAX_COUNT": 1, "X_POSITION": list(range(2, 30)), "Y_POSITION": [5, 10, 15]},
+              {"MAX_COUNT": 1, "X_POSITION": list(range(2, 30)), "Y_POSITION": [20, 25, 28]}]
+    lv = {"LEVEL_LAYOUT": "\n".join(rows), "STATIC_OBJECTS": statics, "DYNAMIC_OBJECTS": dyn, "AGENTS": agents,
+          "DYNAMIC_EXCLUDED_POSITIONS": [[0, 0], [W - 1, 0], [0, H - 1], [W - 1, H - 1]]}
+    n_counters = sum(r.count("-") for r in rows)
+    meta = [{"Switch": 1}, {"Block": 2}, {"Cutboard": 6}, {"Counter": n_counters}, {"Blender": 3}, {"Deliversquare": 4}] + \
+           [{n: c} for n, c in counts[:-1]] + [{"Bread": 6}, {"Agent": 4}]
+    out["huge_32x31"] = (lv, meta)
+
+    # ---- 20 x 20, few objects
+    W = H = 20
+    rows = grid(W, H, (4, 5, 9, 10, 14, 15), 3, 16)
+    statics = [one("Cutboard", 3, 4), one("Cutboard", 16, 15), one("Blender", 0, 8), one("Deliversquare", 9, 0),
+               one("Switch", 1, 12), one("Block", 18, 7)]
+    counts = [("Plate", 4), ("Tomato", 4), ("Lettuce", 3), ("Onion", 3), ("Carrot", 3), ("Banana", 3), ("Bread", 2)]
+    dyn = [{n: {"COUNT": c, "X_POSITION": list(range(W)), "Y_POSITION": list(range(H))}} for n, c in counts]
+    agents = [{"MAX_COUNT": 1, "X_POSITION": [1], "Y_POSITION": [1]}, {"MAX_COUNT": 1, "X_POSITION": [18], "Y_POSITION": [18]},
+              {"MAX_COUNT": 1, "X_POSITION": list(range(2, 18)), "Y_POSITION": [6, 7, 11, 12]}]
+    lv = {"LEVEL_LAYOUT": "\n".join(rows), "STATIC_OBJECTS": statics, "DYNAMIC_OBJECTS": dyn, "AGENTS": agents,
+          "DYNAMIC_EXCLUDED_POSITIONS": [[0, 0], [W - 1, 0], [0, H - 1], [W - 1, H - 1]]}
+    n_counters = sum(r.count("-") for r in rows)
+    meta = [{"Agent": 3}, {"Switch": 1}, {"Block": 1}, {"Cutboard": 2}, {"Counter": n_counters}, {"Blender": 1},
+            {"Deliversquare": 1}] + [{n: c} for n, c in counts[:-1]] + [{"Bread": 4}]
+    out["huge_20x20"] = (lv, meta)
+
+    # ---- 16 x 16 = 256 cells (still the four-cells-per-lane size) with 190 slots.  The reference puts one object per
+    # Counter, so the grid is a solid block of counters inside a one-cell floor ring.
+    W = H = 16
+    rows = grid(W, H, tuple(range(2, 14)), 2, 13)
+    statics = [one("Cutboard", 2, 6), one("Cutboard", 13, 9), one("Blender", 0, 7), one("Deliversquare", 7, 0), one("Deliversquare", 8, 15)]
+    counts = [("Plate", 16)] + [(n, 21) for n in foods] + [("Bread", 3)]
+    assert sum(c for _, c in counts) + 3 == 190
+    dyn = [{n: {"COUNT": c, "X_POSITION": list(range(W)), "Y_POSITION": list(range(H))}} for n, c in counts]
+    agents = [{"MAX_COUNT": 1, "X_POSITION": [1], "Y_POSITION": list(range(1, 15))},
+              {"MAX_COUNT": 1, "X_POSITION": [14], "Y_POSITION": list(range(1, 15))},
+              {"MAX_COUNT": 1, "X_POSITION": list(range(2, 14)), "Y_POSITION": [1, 14]}]
+    lv = {"LEVEL_LAYOUT": "\n".join(rows), "STATIC_OBJECTS": statics, "DYNAMIC_OBJECTS": dyn, "AGENTS": agents,
+          "DYNAMIC_EXCLUDED_POSITIONS": [[0, 0], [15, 0], [0, 15], [15, 15]]}
+    n_counters = sum(r.count("-") for r in rows)
+    meta = [{"Cutboard": 2}, {"Counter": n_counters}, {"Blender": 1}, {"Deliversquare": 2}] + \
+           [{n: c} for n, c in counts[:-1]] + [{"Bread": 6}, {"Agent": 3}]
+    out["huge_objs_16x16"] = (lv, meta)
+    return out
+
+
 def main():
     os.makedirs(LEVEL_DIR, exist_ok=True)
     os.makedirs(META_DIR, exist_ok=True)
@@ -182,6 +256,9 @@ def main():
     for name, lv in levels.items():
         dump_level(os.path.join(LEVEL_DIR, name + ".json"), lv)
     dump_meta(os.path.join(META_DIR, "limits.json"), meta)
+    for name, (lv, meta) in huge_levels().items():
+        dump_level(os.path.join(LEVEL_DIR, name + ".json"), lv)
+        dump_meta(os.path.join(META_DIR, name + ".json"), meta)
     if os.path.isdir(REF):
         for name in ("coop_test", "coexistence_test", "switch_test"):
             with open(os.path.join(REF, "level", name + ".json")) as f:
