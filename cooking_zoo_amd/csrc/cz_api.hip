@@ -219,9 +219,9 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     if (cfg->num_recipes < cfg->num_agents || cfg->num_recipes > MAX_AGENTS)
         return fail(nullptr, "cz_create: need num_agents <= num_recipes <= 4 (one recipe per agent, cooking_env.py:329)");
     // (the quotient table holds 2W-1 x-entries from index 0 and 2H-1 y-entries from index 64, below the constants at 126/127)
-    if (cfg->width < 1 || cfg->height < 1 || cfg->width > 32 || cfg->height > 31)
-        return fail(nullptr, "cz_create: grid %dx%d unsupported (W <= 32, H <= 31)", cfg->width, cfg->height);
-    static_assert(2 * 32 - 1 <= LUT_Y0 && LUT_Y0 + 2 * 31 - 1 <= LUT_ZERO, "quotient table layout");
+    if (cfg->width < 1 || cfg->height < 1 || cfg->width > 32 || cfg->height > 32)
+        return fail(nullptr, "cz_create: grid %dx%d unsupported (W <= 32, H <= 32)", cfg->width, cfg->height);
+    static_assert(2 * 32 - 1 <= LUT_Y0 && LUT_Y0 + 2 * 32 - 1 <= LUT_ZERO, "quotient table layout");
     if (cfg->max_dyn < 1 || cfg->max_dyn > 255) return fail(nullptr, "cz_create: max_dyn must be 1..255 (slot + 1 is an 8-bit field)");
     if (cfg->action_scheme != 1 && cfg->action_scheme != 3)
         return fail(nullptr, "cz_create: action_scheme must be 1 or 3 (scheme2 is unusable in the reference)");

@@ -45,7 +45,7 @@ enum : uint32_t { COND_NONE = 0, COND_CHOPPED, COND_MASHED, COND_NOT_CHOPPED, CO
 enum : uint32_t { W_T = 0, W_MARKS, W_LAYOUT, W_STATUS, W_EPISODE, W_RECIPES, W_POOL, W_MARKS_HI };   // word 7: wide tables only
 enum : uint32_t { ST_DONE = 1, ST_TERM = 2, ST_TRUNC = 4 };
 // observation descriptor (one u32 per feature): (image halfword index * 2) | (axis code * 4) << 16  -- soa.py
-constexpr int LUT_Y0 = 64, LUT_ZERO = 126, LUT_ONE = 127;   // + entries 128..255 = 0.0, the "absent" zone
+constexpr int LUT_Y0 = 63, LUT_ZERO = 126, LUT_ONE = 127;   // + entries 128..255 = 0.0, the "absent" zone
 // per-env statistics: u32 words and doubles
 enum : uint32_t { SU_EPISODES = 0, SU_STEPS, SU_LENSUM, SU_TRUNC, SU_TERM, SU_COMPLETED0, SU_WORDS = 16 };
 enum : uint32_t { SF_CUR0 = 0, SF_SUM0 = 4, SF_WORDS = 8 };
@@ -66,7 +66,7 @@ struct Params {
     uint64_t seed;
     double recipe_reward, recipe_penalty, node_reward, time_penalty_step;
     double reward_idle;            // the reward formula evaluated with no goal change (host, same op order)
-    const double *lut;             // [256] host-computed quotients: [i] (i-(W-1))/W, [64+i] (i-(H-1))/H, [126] 0, [127] 1, rest 0
+    const double *lut;             // [256] host-computed quotients: [i] (i-(W-1))/W, [63+i] (i-(H-1))/H, [126] 0, [127] 1, rest 0
     uint32_t inv_w;                // ceil(65536 / W): c / W == (c * inv_w) >> 16 for every cell index c
     int32_t N, A, W, H, D, F, RW, scheme, max_steps, end_all, R, auto_reset, L;
     int32_t T;                     // fused steps per launch (1 for cz_step)

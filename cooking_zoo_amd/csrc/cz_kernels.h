@@ -54,7 +54,7 @@ template <int CPL> constexpr int envs_per_wg() { return CPL > 4 ? 4 : ENVS_PER_W
 constexpr int OBS_PAIRS = 3;       // feature pairs per lane and chunk: 3 x 128 = 384 features per chunk
 constexpr int OBS_CHUNK = 2 * OBS_PAIRS;   // descriptor words held per lane
 
-// (the quotient table `lut` itself is shared by the waves of a workgroup: [0..2W-2] (i-(W-1))/W | [64..64+2H-2] (i-(H-1))/H |
+// (the quotient table `lut` itself is shared by the waves of a workgroup: [0..2W-2] (i-(W-1))/W | [63..63+2H-2] (i-(H-1))/H |
 // [126] 0.0 | [127] 1.0 | [128..255] 0.0)
 template <int CPL>
 struct Lds {

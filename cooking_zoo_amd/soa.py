@@ -67,22 +67,22 @@ MAX_AGENTS = 4
 
 # ---- observation descriptor: one u32 per feature =  (image halfword index * 2) | (axis code * 4) << 16
 # The kernel keeps, per env, an LDS "image" of halfwords; every halfword is a byte offset into a 256-entry table of
-# doubles (lut):  lut[i] = (i-(W-1))/W for i < 2W-1,  lut[64+i] = (i-(H-1))/H,  lut[126] = 0.0,  lut[127] = 1.0,
+# doubles (lut):  lut[i] = (i-(W-1))/W for i < 2W-1,  lut[63+i] = (i-(H-1))/H,  lut[126] = 0.0,  lut[127] = 1.0,
 # lut[128..255] = 0.0 (the "absent" zone: every halfword of a dead slot points at entry 255, and stays inside the
 # zone after an agent coordinate is subtracted).  Image layout (halfword indices):
-#   slot s    IMG_OBJ0 + 6 s : x+W-1 | y+64+H-1 | 126+!done | 126+chopped | 126+mashed | 127
-#   cell c    IMG_CELL0 + 4 c: x+W-1 | y+64+H-1 | 126+(switch_active or block walkable) | 127
-#   agent a   IMG_AG0 + 8 a  : x+W-1 | y+64+H-1 | 126+(o==1) | .. | 126+(o==4) | 127 | pad
+#   slot s    IMG_OBJ0 + 6 s : x+W-1 | y+63+H-1 | 126+!done | 126+chopped | 126+mashed | 127
+#   cell c    IMG_CELL0 + 4 c: x+W-1 | y+63+H-1 | 126+(switch_active or block walkable) | 127
+#   agent a   IMG_AG0 + 8 a  : x+W-1 | y+63+H-1 | 126+(o==1) | .. | 126+(o==4) | 127 | pad
 #   IMG_ZERO                 : 255
 # A feature value for observer a is  lut[image[hw] - sub[a][code]]  with the axis code choosing what is subtracted:
 #   0 nothing, 1 ax, 2 ay, 4+2j / 5+2j: ax / ay unless a == j (an agent's own position is absolute, cooking_env.py:366-368)
 IMG_OBJ0, IMG_CELL0, IMG_AG0, IMG_ZERO, IMG_HALFWORDS = 0, 768, 1792, 1824, 1826
-# Batches beyond 128 slots or 256 cells run on the "huge" kernel instance (up to 255 slots, 32 x 31 cells), whose image
+# Batches beyond 128 slots or 256 cells run on the "huge" kernel instance (up to 255 slots, 32 x 32 cells), whose image
 # has room for 256 slots and 1024 cells (cz_kernels.h Img<16>):
 HUGE_IMG_OBJ0, HUGE_IMG_CELL0, HUGE_IMG_AG0, HUGE_IMG_ZERO = 0, 1536, 5632, 5664
-MAX_DYN, MAX_W, MAX_H = 255, 32, 31          # (slot + 1) is an 8-bit field; the quotient table holds 2W-1 <= 63, 2H-1 <= 61 entries
+MAX_DYN, MAX_W, MAX_H = 255, 32, 32          # (slot + 1) is an 8-bit field; the quotient table holds 2W-1 <= 63 and 2H-1 <= 63 entries
 AX_NONE, AX_X, AX_Y = 0, 1, 2
-LUT_Y0, LUT_ZERO, LUT_ONE, LUT_ABSENT, LUT_SIZE = 64, 126, 127, 255, 256
+LUT_Y0, LUT_ZERO, LUT_ONE, LUT_ABSENT, LUT_SIZE = 63, 126, 127, 255, 256
 
 
 def desc_word(hw, code=0):

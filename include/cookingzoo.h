@@ -36,7 +36,7 @@ typedef struct cz_handle_s *cz_handle;
 typedef struct cz_config {
     int32_t num_envs;            /* env instances owned by this handle (one wavefront each)          */
     int32_t num_agents;          /* A <= 4            (cooking_env.py:76, COLORS cooking_world.py:21) */
-    int32_t width, height;       /* grid, W <= 32, H <= 31 (parsing.py:17-18)                         */
+    int32_t width, height;       /* grid, W <= 32, H <= 32 (parsing.py:17-18)                         */
     int32_t max_dyn;             /* D dynamic-object slots per env, <= 255                            */
     int32_t feat_len;            /* F features per agent (cooking_env.py:114-117)                     */
     int32_t action_scheme;       /* 1 or 3            (cooking_env.py:60; scheme2 is dead upstream)   */

@@ -18,7 +18,7 @@ def cfg(**kw):
 
 
 @pytest.mark.parametrize("bad,msg", [
-    (dict(num_agents=5), "num_agents"), (dict(num_recipes=1), "num_recipes"), (dict(width=40), "grid"), (dict(width=8, height=32), "grid"),
+    (dict(num_agents=5), "num_agents"), (dict(num_recipes=1), "num_recipes"), (dict(width=40), "grid"), (dict(width=8, height=33), "grid"),
     (dict(max_dyn=256), "max_dyn"), (dict(action_scheme=2), "scheme2"), (dict(device_id=99), "device_id"),
     (dict(num_envs=0), "num_envs"),
 ])

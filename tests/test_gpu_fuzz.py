@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 LEVELS = [("coop_test", "example", 2), ("coexistence_test", "example", 2), ("switch_test", "example", 2),
           ("large_16x16", "large_16x16", 4), ("crowded_6x5", "crowded_6x5", 4), ("edge_8x8", "edge", 3),
           ("edge_9x8", "edge", 3), ("edge_empty", "edge", 3), ("limit_32x8", "limits", 3), ("limit_8x31", "limits", 3), ("dense_16x16", "dense_16x16", 4),
-          ("huge_32x31", "huge_32x31", 4), ("huge_20x20", "huge_20x20", 3), ("huge_objs_16x16", "huge_objs_16x16", 3)]
+          ("huge_32x32", "huge_32x32", 4), ("huge_20x20", "huge_20x20", 3), ("huge_objs_16x16", "huge_objs_16x16", 3)]
 BOOK = ["TomatoSalad", "TomatoLettuceSalad", "CarrotBanana", "MashedCarrotBanana", "CucumberOnion", "AppleWatermelon",
         "TomatoLettuceOnionSalad", "no_recipe"]
 N_CASES = int(os.environ.get("CZ_FUZZ_CASES", "6"))

@@ -50,7 +50,7 @@ FAMILIES = [
     ("limit_32x8", "limits", 2, ["TomatoSalad", "CarrotBanana"], "scheme3"),
     ("limit_8x31", "limits", 3, ["TomatoSalad", "CarrotBanana", "AppleWatermelon"], "scheme1"),
     # the third kernel instance (more than 128 slots or 256 cells)
-    ("huge_32x31", "huge_32x31", 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"], "scheme3"),
+    ("huge_32x32", "huge_32x32", 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"], "scheme3"),
     ("huge_20x20", "huge_20x20", 3, ["TomatoLettuceSalad", "MashedCarrotBanana", "TomatoSalad"], "scheme1"),
     ("huge_objs_16x16", "huge_objs_16x16", 2, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3"),
 ]

@@ -71,14 +71,14 @@ def eval_descriptor(desc, d, rec):
         x, y, c, fl = soa.unpack_dyn0(rec[d.dyn0_word0 + s_])
         if fl & soa.DYN_ALIVE:
             ch, ma = bool(fl & soa.DYN_CHOPPED), bool(fl & soa.DYN_MASHED)
-            img[obj0 + 6 * s_:obj0 + 6 * s_ + 6] = [x + d.W - 1, y + 64 + d.H - 1, 126 + (not (ch or ma)),
+            img[obj0 + 6 * s_:obj0 + 6 * s_ + 6] = [x + d.W - 1, y + soa.LUT_Y0 + d.H - 1, 126 + (not (ch or ma)),
                                                                   126 + ch, 126 + ma, 127]
     for c in range(d.C):
         f = bool(cells[c] & (soa.CELL_ACTIVE | soa.CELL_WALK))
-        img[cell0 + 4 * c:cell0 + 4 * c + 4] = [c % d.W + d.W - 1, c // d.W + 64 + d.H - 1, 126 + f, 127]
+        img[cell0 + 4 * c:cell0 + 4 * c + 4] = [c % d.W + d.W - 1, c // d.W + soa.LUT_Y0 + d.H - 1, 126 + f, 127]
     for a in range(d.A):
         x, y, o, _ = ag[a]
-        img[ag0 + 8 * a:ag0 + 8 * a + 7] = [x + d.W - 1, y + 64 + d.H - 1] + [126 + (o == k) for k in (1, 2, 3, 4)] + [127]
+        img[ag0 + 8 * a:ag0 + 8 * a + 7] = [x + d.W - 1, y + soa.LUT_Y0 + d.H - 1] + [126 + (o == k) for k in (1, 2, 3, 4)] + [127]
     out = np.zeros((d.A, d.F))
     for f, w in enumerate(desc):
         w = int(w)

@@ -721,16 +721,16 @@ def main():
     # beyond 128 slots / 256 cells: the third kernel instance (tools/make_levels.py huge_levels)
     lvl = lambda n: os.path.join(REPO, "cooking_zoo_amd", "utils", "level", n + ".json")
     mta = lambda n: os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", n + ".json")
-    if os.path.exists(lvl("huge_32x31")):
-        sets["huge_32x31_4agents"] = lambda: run_set(
-            "huge_32x31_4agents",
-            base_cfg(lvl("huge_32x31"), 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"], max_steps=100,
-                     meta=mta("huge_32x31")),
+    if os.path.exists(lvl("huge_32x32")):
+        sets["huge_32x32_4agents"] = lambda: run_set(
+            "huge_32x32_4agents",
+            base_cfg(lvl("huge_32x32"), 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"], max_steps=100,
+                     meta=mta("huge_32x32")),
             [(800, "bumper", 100), (801, "uniform", 100), (802, "mixed", 100)], args.out)
-        sets["huge_32x31_scheme1"] = lambda: run_set(
-            "huge_32x31_scheme1",
-            base_cfg(lvl("huge_32x31"), 2, ["TomatoLettuceOnionSalad", "MashedCarrotBanana"], scheme="scheme1", max_steps=60,
-                     meta=mta("huge_32x31")),
+        sets["huge_32x32_scheme1"] = lambda: run_set(
+            "huge_32x32_scheme1",
+            base_cfg(lvl("huge_32x32"), 2, ["TomatoLettuceOnionSalad", "MashedCarrotBanana"], scheme="scheme1", max_steps=60,
+                     meta=mta("huge_32x32")),
             [(810, "bumper", 60), (811, "uniform", 60)], args.out)
     if os.path.exists(lvl("huge_20x20")):
         sets["huge_20x20"] = lambda: run_set(

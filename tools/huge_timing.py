@@ -14,7 +14,7 @@ CASES = [("coop_test", "example", 2, ["TomatoLettuceSalad", "CarrotBanana"]),
          ("large_16x16", "large_16x16", 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"]),
          ("huge_20x20", "huge_20x20", 3, ["TomatoLettuceSalad", "MashedCarrotBanana", "TomatoSalad"]),
          ("huge_objs_16x16", "huge_objs_16x16", 3, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon"]),
-         ("huge_32x31", "huge_32x31", 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"])]
+         ("huge_32x32", "huge_32x32", 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"])]
 
 
 def main():

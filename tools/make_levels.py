@@ -138,7 +138,7 @@ def dense_16x16():
 
 
 def limit_levels():
-    """the largest grids the kernels take: 32 columns (W <= 32) and 31 rows (H <= 31), both close to the 256-cell cap;
+    """long thin grids, 32 columns and 31 rows, both close to the 256-cell cap of the middle kernel instance;
     they exercise the ends of the observation quotient table ((x - ax) / W for |x - ax| up to 31, (y - ay) / H up to 30)"""
     out = {}
     one = lambda name, x, y: {name: {"COUNT": 1, "X_POSITION": [x], "Y_POSITION": [y]}}
@@ -164,7 +164,7 @@ def limit_levels():
 
 def huge_levels():
     """beyond 128 slots / 256 cells (the third kernel instance):
-    * huge_32x31: the largest grid there is (992 cells) with every one of the 255 slots in use, 4 agents,
+    * huge_32x32: the largest grid there is (1024 cells) with every one of the 255 slots in use, 4 agents,
     * huge_20x20: 400 cells with few objects (only the cell count is over the old cap),
     * huge_objs_16x16: 256 cells with 190 slots (only the object count is over the old cap)"""
     out = {}
@@ -178,27 +178,27 @@ def huge_levels():
                                 for x in range(W)))
         return rows
 
-    # ---- 32 x 31, all 255 slots
-    W, H = 32, 31
-    rows = grid(W, H, (3, 4, 8, 9, 13, 14, 18, 19, 23, 24, 27), 2, 29)
+    # ---- 32 x 32, all 255 slots
+    W, H = 32, 32
+    rows = grid(W, H, (3, 4, 8, 9, 13, 14, 18, 19, 23, 24, 28), 2, 29)
     statics = [one("Cutboard", x, y) for x, y in [(2, 3), (29, 4), (10, 13), (20, 14), (2, 23), (29, 24)]]
-    statics += [one("Blender", 0, 10), one("Blender", 31, 20), one("Blender", 15, 27)]
-    statics += [{"Deliversquare": {"COUNT": 3, "X_POSITION": [5, 16, 26], "Y_POSITION": [0]}}, one("Deliversquare", 16, 30)]
+    statics += [one("Blender", 0, 10), one("Blender", 31, 20), one("Blender", 15, 28)]
+    statics += [{"Deliversquare": {"COUNT": 3, "X_POSITION": [5, 16, 26], "Y_POSITION": [0]}}, one("Deliversquare", 16, 31)]
     # (one Switch only: a second one crashes the reference, SURVEY A.8 -- Switch has no switch_state)
     statics += [one("Switch", 1, 6), one("Block", 1, 11), one("Block", 30, 16)]
     counts = [("Plate", 25)] + [(n, 28) for n in foods] + [("Bread", 3)]
     assert sum(c for _, c in counts) + 3 == 255
     dyn = [{n: {"COUNT": c, "X_POSITION": list(range(W)), "Y_POSITION": list(range(H))}} for n, c in counts]
     agents = [{"MAX_COUNT": 1, "X_POSITION": [1], "Y_POSITION": [1]},
-              {"MAX_COUNT": 1, "X_POSITION": [30], "Y_POSITION": [29]},
+              {"MAX_COUNT": 1, "X_POSITION": [30], "Y_POSITION": [30]},
               {"MAX_COUNT": 1, "X_POSITION": list(range(2, 30)), "Y_POSITION": [5, 10, 15]},
-              {"MAX_COUNT": 1, "X_POSITION": list(range(2, 30)), "Y_POSITION": [20, 25, 28]}]
+              {"MAX_COUNT": 1, "X_POSITION": list(range(2, 30)), "Y_POSITION": [20, 25, 29]}]
     lv = {"LEVEL_LAYOUT": "\n".join(rows), "STATIC_OBJECTS": statics, "DYNAMIC_OBJECTS": dyn, "AGENTS": agents,
           "DYNAMIC_EXCLUDED_POSITIONS": [[0, 0], [W - 1, 0], [0, H - 1], [W - 1, H - 1]]}
     n_counters = sum(r.count("-") for r in rows)
     meta = [{"Switch": 1}, {"Block": 2}, {"Cutboard": 6}, {"Counter": n_counters}, {"Blender": 3}, {"Deliversquare": 4}] + \
            [{n: c} for n, c in counts[:-1]] + [{"Bread": 6}, {"Agent": 4}]
-    out["huge_32x31"] = (lv, meta)
+    out["huge_32x32"] = (lv, meta)
 
     # ---- 20 x 20, few objects
     W = H = 20
