@@ -337,7 +337,7 @@ class AECCookingEnvironment:
     `step(action)` / `last()` / `agent_iter()` (cooking_env.py:215-241; gym id cookingZooEnv-v0).
 
     Agents act in turn; the world advances once the last agent of the round has chosen (one batched device step).
-    Bookkeeping follows the reference call by call (tests/golden/aec_traces.json), including two things a PettingZoo
+    Bookkeeping follows the reference call by call (tests/golden/aec_traces.json.gz), including two things a PettingZoo
     user would not expect: rewards are zeroed for everybody on every sub-step, and after each call the cumulative
     reward that is cleared is the LAST agent's (the loop variable of cooking_env.py:229 shadows the acting agent), so
     every other agent's `last()` reward keeps growing over the episode.

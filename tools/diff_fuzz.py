@@ -61,6 +61,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--episodes", type=int, default=200)
     ap.add_argument("--seed0", type=int, default=1000)
+    ap.add_argument("--families", default="base", choices=["base", "all"],
+                    help="base: the BASELINE levels; all: also the edge / limit / dense / huge levels (slow in the reference)")
     args = ap.parse_args()
     L = os.path.join(REPO, "cooking_zoo_amd", "utils", "level")
     M = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files")
@@ -73,7 +75,14 @@ def main():
         seed = args.seed0 + i
         kind = i % 6
         scheme = "scheme1" if (i // 6) % 3 == 2 else "scheme3"
-        if kind in (0, 1):
+        own = lambda name, meta_name: (os.path.join(L, name + ".json"), os.path.join(M, meta_name + ".json"))
+        extra = [("edge_8x8", "edge", 3), ("edge_9x8", "edge", 3), ("edge_empty", "edge", 2), ("limit_32x8", "limits", 3),
+                 ("limit_8x31", "limits", 3), ("dense_16x16", "dense_16x16", 4), ("huge_32x32", "huge_32x32", 4),
+                 ("huge_20x20", "huge_20x20", 3), ("huge_objs_16x16", "huge_objs_16x16", 3)]
+        if args.families == "all" and i % 2 == 1:
+            name, meta_name, max_agents = extra[(i // 2) % len(extra)]
+            (lvl, meta), A = own(name, meta_name), int(rng.integers(1, max_agents + 1))
+        elif kind in (0, 1):
             lvl, meta, A = "coop_test", "example", 1 + (i % 2)
         elif kind == 2:
             lvl, meta, A = "coexistence_test", "example", 2
