@@ -242,6 +242,7 @@ def worker(args):
     if Wm > 0:
         run_steps(Wm, 0)
     L.cz_launch_counts(h, None, None, 1)
+    L.cz_chain_counts(h, None, 1)
     elapsed, steps_done = [], []
     for r in range(R):
         s0 = env.stats()["env_steps"]
@@ -252,8 +253,9 @@ def worker(args):
         elapsed.append(time.perf_counter() - t0)
         barrier()
         steps_done.append(env.stats()["env_steps"] - s0)       # world steps executed (auto-reset passes are not counted)
-    g_k, d_k = C.c_int64(), C.c_int64()
+    g_k, d_k, c_k = C.c_int64(), C.c_int64(), C.c_int64()
     L.cz_launch_counts(h, C.byref(g_k), C.byref(d_k), 0)
+    L.cz_chain_counts(h, C.byref(c_k), 0)
 
     # dominant-kernel duration: HIP events on the kernels' own stream around max(R*K, 4000) launches issued back to back (the
     # host <-> GPU round trip of a synchronised region, ~20 us on this platform whatever K is, is not kernel time)
@@ -327,9 +329,11 @@ def worker(args):
         L.cz_runtime_paths(rccl_path, hip_path, 512)
         b_alg = algorithmic_bytes_per_env_step(env)
         achieved = b_alg * N / (kernel_med * 1e-6) / 1e9
-        total_k = g_k.value + d_k.value
-        api = (f"cz_step_device_ring: one kernel launch per env step; of the {total_k} timed launches {g_k.value} were replayed "
-               f"from HIP graphs of {K if K <= 256 else 'up to 256'} launches and {d_k.value} launched directly; "
+        total_k = g_k.value + d_k.value + c_k.value
+        api = (f"cz_step_device_ring: one kernel launch per env step; of the {total_k} timed launches {c_k.value} went out as "
+               f"overlapped launches (two streams alternately, each env's step ordered after that env's previous step by a "
+               f"sequence word instead of a launch boundary), {g_k.value} were replayed from HIP graphs of "
+               f"{K if K <= 256 else 'up to 256'} launches and {d_k.value} launched directly; "
                f"actions/obs/rewards/flags resident in HBM")
         line = {
             "metric": "env-steps/sec at N parallel envs (1/2/4/8 GPU) + achieved HBM GB/s",

@@ -125,6 +125,13 @@ struct cz_handle_s {
     Params P;
     hipStream_t stream = nullptr;      // the stream every call of this handle is ordered on
     hipStream_t own_stream = nullptr;  // the one cz_create made (cz_set_stream may point `stream` at a caller's)
+    // overlapped ("chained") runs of cz_step_device_ring: odd steps go to aux_stream (SEQ_* in cz_device.h)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool chain_enabled = true;         // CZ_CHAIN=0: runs are ordered by launch boundaries only (graph replay)
+    uint32_t seq_counter = 0;          // number of the next chained launch (mod 2^30)
+    uint32_t *h_chain_err = nullptr;   // pinned, device-mapped: set by a wave whose hand-off never came
+    int64_t n_chained_kernels = 0;
     Launchers kl;
     int n_layouts = 0, n_recipes = 0;
     uint32_t *d_state = nullptr, *d_lay_init = nullptr, *d_lay_desc = nullptr, *d_recipes = nullptr;
@@ -245,6 +252,11 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     CREATE_CHK(hipSetDevice(cfg->device_id));
     CREATE_CHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
+    CREATE_CHK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    CREATE_CHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    CREATE_CHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    CREATE_CHK(hipHostMalloc((void **)&h->h_chain_err, 64, hipHostMallocMapped));
+    *h->h_chain_err = 0;
     CREATE_CHK(hipEventCreate(&h->ev0));
     CREATE_CHK(hipEventCreate(&h->ev1));
     Params &P = h->P;
@@ -262,6 +274,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     P.stop = -1;
     if (const char *s = getenv("CZ_WT")) h->wt_override = atoi(s);
     if (const char *s = getenv("CZ_GRAPHS")) h->graphs_enabled = atoi(s) != 0;
+    if (const char *s = getenv("CZ_CHAIN")) h->chain_enabled = atoi(s) != 0;
     if (const char *s = getenv("CZ_RING_PREFIX")) h->ring_prefix = atoi(s) < 0 ? 0 : (atoi(s) > 16 ? 16 : atoi(s));
     if (const char *s = getenv("CZ_ZERO_COPY_BYTES")) h->zero_copy_bytes = (size_t)atoll(s);
     if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // honoured by the diagnostic build only
@@ -276,8 +289,15 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
         P.reward_idle = x;
     }
     const size_t N = (size_t)P.N;
-    CREATE_CHK(hipMalloc(&h->d_state, N * P.RW * 4));
-    CREATE_CHK(hipMemsetAsync(h->d_state, 0, N * P.RW * 4, h->stream));
+    // the records, then one sequence word per env, 64 B apart (hand-off of overlapped launches, SEQ_* in cz_device.h)
+    const size_t state_bytes = N * P.RW * 4 + N * SEQ_STRIDE_WORDS * 4;
+    CREATE_CHK(hipMalloc(&h->d_state, state_bytes));
+    CREATE_CHK(hipMemsetAsync(h->d_state, 0, state_bytes, h->stream));
+    {
+        void *dp = nullptr;
+        CREATE_CHK(hipHostGetDevicePointer(&dp, h->h_chain_err, 0));
+        P.chain_err = (uint32_t *)dp;
+    }
     CREATE_CHK(hipMalloc(&h->d_stat_u, N * SU_WORDS * 4));
     CREATE_CHK(hipMalloc(&h->d_stat_f, N * SF_WORDS * 8));
     CREATE_CHK(hipMemsetAsync(h->d_stat_u, 0, N * SU_WORDS * 4, h->stream));
@@ -313,6 +333,7 @@ extern "C" int cz_destroy(cz_handle h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device_id);
     (void)hipStreamSynchronize(h->stream);
+    if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (h->comm && h->rccl) {
         typedef int (*destroy_t)(void *);
         destroy_t f = (destroy_t)dlsym(h->rccl, "ncclCommDestroy");
@@ -327,6 +348,10 @@ extern "C" int cz_destroy(cz_handle h) {
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->h_marks) (void)hipHostFree(h->h_marks);
+    if (h->h_chain_err) (void)hipHostFree(h->h_chain_err);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     for (hipEvent_t e : h->kev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -350,6 +375,8 @@ extern "C" int32_t cz_record_words(cz_handle h) { return h ? h->P.RW : 0; }
 extern "C" int cz_sync(cz_handle h) {
     if (!h) return fail(nullptr, "null handle");
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->h_chain_err && *(volatile uint32_t *)h->h_chain_err)
+        return fail(h, "cz_sync: an overlapped launch gave up waiting for its predecessor (the envs' states are no longer trustworthy)");
     return 0;
 }
 
@@ -533,7 +560,8 @@ static int ready(cz_handle h) {
     return 0;
 }
 
-static int launch_step(cz_handle h, Params &P) {
+static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr) {
+    if (!stream) stream = h->stream;
     // write-through observation stores pay when the launch is short enough for the end-of-kernel L2 write-back to be
     // exposed: one step of a moderate batch.  (CZ_WT=0/1 overrides, for experiments.)
     P.wt = (P.actions != nullptr && (size_t)P.N * P.A * P.F * 8 <= ((size_t)128 << 20)) ? 1 : 0;
@@ -547,10 +575,34 @@ static int launch_step(cz_handle h, Params &P) {
         }
         e0 = h->kev[h->kev_used]; e1 = h->kev[h->kev_used + 1];
         h->kev_used += 2;
-        HIPCHK(h, hipEventRecord(e0, h->stream));
+        HIPCHK(h, hipEventRecord(e0, stream));
     }
-    HIPCHK(h, h->kl.step(P, h->stream));
-    if (h->ktime) HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, h->kl.step(P, stream));
+    if (h->ktime) HIPCHK(h, hipEventRecord(e1, stream));
+    return 0;
+}
+// can this launch be part of an overlapped run?  (one-step kernel with write-through observation stores: two waves of
+// different launches write the same output bytes, so those must not sit dirty in two L2s)
+static bool chainable(cz_handle h, const Params &P) {
+    if (!h->chain_enabled || h->ktime || !P.actions) return false;
+    if (h->wt_override >= 0) return h->wt_override == 1;
+    return (size_t)P.N * P.A * P.F * 8 <= ((size_t)128 << 20);
+}
+// K steps of an overlapped run: even steps on the handle's stream, odd steps on aux_stream, every launch but the first
+// waits per env for its predecessor's sequence number (cz_kernels.h k_step) instead of for the whole previous kernel
+static int launch_chain(cz_handle h, Params &P, int32_t K, const int32_t *d_ring, int64_t stride, int32_t period, int32_t first_slot) {
+    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+    for (int32_t k = 0; k < K; ++k) {
+        P.actions = d_ring + (int64_t)(((int64_t)first_slot + k) % period) * stride;
+        P.seq = SEQ_PUBLISH | (k > 0 ? SEQ_WAIT : 0u) | ((h->seq_counter + (uint32_t)k) & SEQ_MASK);
+        if (launch_step(h, P, (k & 1) ? h->aux_stream : h->stream)) return 1;
+    }
+    P.seq = 0;
+    h->seq_counter = (h->seq_counter + (uint32_t)K) & SEQ_MASK;
+    HIPCHK(h, hipEventRecord(h->ev_join, h->aux_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    h->n_chained_kernels += K;
     return 0;
 }
 
@@ -709,6 +761,10 @@ static int ring_walk(cz_handle h, int32_t K, const int32_t *d_ring, int64_t stri
                      double *d_rewards, uint8_t *d_term, uint8_t *d_trunc, bool launch) {
     Params P = h->P;
     P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
+    P.actions = d_ring;
+    // (overlapped runs are launched directly: captured into a graph as two parallel chains they still overlap, but replay
+    // costs 0.2 us per launch more and a 20-step region 1 us per step more than direct launches on two streams)
+    if (K >= 2 && chainable(h, P)) return launch ? launch_chain(h, P, K, d_ring, stride, period, first_slot) : 0;
     const bool graphs = ring_select(h, d_ring, stride, period, d_obs, d_rewards, d_term, d_trunc);
     int32_t k = 0;
     while (k < K) {
@@ -758,6 +814,13 @@ extern "C" int cz_step_device_ring(cz_handle h, int32_t K, const int32_t *d_ring
     if (!d_ring || K < 1 || period < 1 || first_slot < 0 || first_slot >= period) return fail(h, "cz_step_device_ring: bad arguments");
     if (set_device(h)) return 1;
     return ring_walk(h, K, d_ring, stride, period, first_slot, d_obs, d_rewards, d_term, d_trunc, true);
+}
+// how many step kernels of this handle went out as overlapped launches (cz_step_device_ring only); reset != 0 zeroes it
+extern "C" int cz_chain_counts(cz_handle h, int64_t *chained_kernels, int32_t reset) {
+    if (!h) return fail(nullptr, "null handle");
+    if (chained_kernels) *chained_kernels = h->n_chained_kernels;
+    if (reset) h->n_chained_kernels = 0;
+    return 0;
 }
 // how many step kernels of this handle were replayed from graphs / launched directly (cz_step_device_ring only);
 // reset != 0 zeroes the counters after reading

@@ -76,8 +76,18 @@ struct Params {
     int32_t walk_touches;          // 1 if carrying an object across cells can change a recipe mark (see cz_load_recipes)
     int32_t wide;                  // 1: wide recipe tables (up to 16 nodes per graph, marks in record words 1 and 7)
     unsigned long long *stamps;    // diagnostic build only: [N][8] s_memtime stamps (nullptr in the shipped library)
+    uint32_t *chain_err;           // pinned host word: a chained launch whose hand-off never came sets it (cz_sync fails on it)
     int32_t stop;                  // diagnostic build only: phase index after which the kernel returns (CZ_STOP), else -1
+    uint32_t seq;                  // per-env hand-off of overlapped launches (SEQ_*); travels as a leading scalar argument
 };
+// Overlapped ("chained") launches: consecutive step kernels of a run go to two streams alternately, so a kernel may start
+// while its predecessor still runs; what orders them is a sequence word per env (64 B apart, right behind the records):
+// a wave waits until its env's word equals the launch's number, steps, and publishes number + 1.  The launch boundary
+// (1.6 us + start skew on this part) then hides behind the other kernel's work.  Everything a step reads of its
+// predecessor's (the record, the per-env statistics) therefore moves with device-scope loads and write-through stores:
+// the L2 of another XCD is not coherent for ordinary accesses between launch boundaries.
+constexpr uint32_t SEQ_PUBLISH = 1u << 31, SEQ_WAIT = 1u << 30, SEQ_MASK = SEQ_WAIT - 1u;
+constexpr int SEQ_STRIDE_WORDS = 16;
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rdl(uint32_t v, int l) { return __builtin_amdgcn_readlane(v, l); }

@@ -27,7 +27,7 @@ namespace cz {
 // optimiser cannot see through -- otherwise every one of them is fetched at kernel entry and held in SGPRs for the whole
 // kernel (~30 SGPRs: spills in the non-fused kernel, ~90 spilled SGPRs in the fused one).
 typedef const __attribute__((address_space(4))) Params *KParams;
-struct StepArgsMirror { uint32_t *a; const int32_t *b; const double *c; int32_t i[7]; Params p; };   // k_step's argument list
+struct StepArgsMirror { uint32_t *a; const int32_t *b; const double *c; int32_t i[8]; Params p; };   // k_step's argument list
 __device__ __forceinline__ KParams late_params(unsigned offset) {
     const __attribute__((address_space(4))) char *k =
         (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -81,26 +81,46 @@ __device__ __forceinline__ void stg_wt(void *sbase, uint32_t voff, T v) {
     __hip_atomic_store(reinterpret_cast<T *>(reinterpret_cast<char *>(sbase) + voff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// device-scope load (`global_load ... sc1`): does not hit a line that this XCD's L2 fetched before another XCD rewrote it.
+// Used, with stg_wt, for everything one step hands to the next (see SEQ_* in cz_device.h); after a launch boundary the L2
+// is cold anyway, so ordinary launches lose nothing.
+template <class T>
+__device__ __forceinline__ T ldg_dev(const void *sbase, uint32_t voff) {
+    return __hip_atomic_load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(sbase) + voff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 
 // Loads are clamped instead of exec-masked (no branches): every address stays inside the record.
+// `dev` (wave-uniform): the launch is part of an overlapped run -> device-scope flavour; ordinary launches keep cached
+// loads and write-back stores (the launch boundary publishes them), which is 0.7 us per launch faster there
+template <class T>
+__device__ __forceinline__ T ldrec(bool dev, const void *sbase, uint32_t voff) {
+    if (dev) return ldg_dev<T>(sbase, voff);
+    return ldg<T>(sbase, voff);
+}
+template <class T>
+__device__ __forceinline__ void strec(bool dev, void *sbase, uint32_t voff, T v) {
+    if (dev) stg_wt<T>(sbase, voff, v);
+    else stg<T>(sbase, voff, v);
+}
 template <int OPL, int CPL, int NA>
-__device__ __forceinline__ void load_env(const Params &P, Env<OPL, CPL, NA> &e, const Ctx &cx, const uint32_t *__restrict__ rec) {
+__device__ __forceinline__ void load_env(const Params &P, Env<OPL, CPL, NA> &e, const Ctx &cx, const uint32_t *__restrict__ rec, bool dev = false) {
     const uint32_t lane = (uint32_t)cx.lane;
-    const uint32_t h = ldg<uint32_t>(rec, (lane & 7u) * 4u);                         // header words
-    const uint32_t aw = ldg<uint32_t>(rec, (AGENT_WORD0 + (lane & 3u)) * 4u);        // agent words, lane a = agent a
+    const uint32_t h = ldrec<uint32_t>(dev, rec, (lane & 7u) * 4u);                         // header words
+    const uint32_t aw = ldrec<uint32_t>(dev, rec, (AGENT_WORD0 + (lane & 3u)) * 4u);        // agent words, lane a = agent a
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const uint32_t c = lane + 64u * k;
-        const uint32_t v = ldg<uint8_t>(rec, CELL_WORD0 * 4u + min(c, (uint32_t)cx.C - 1u));
+        const uint32_t v = ldrec<uint8_t>(dev, rec, CELL_WORD0 * 4u + min(c, (uint32_t)cx.C - 1u));
         e.cell[k] = (c < (uint32_t)cx.C) ? v : 0u;
     }
 #pragma unroll
     for (int k = 0; k < OPL; ++k) {
         const uint32_t s = lane + 64u * k, sc = min(s, (uint32_t)cx.D - 1u);
-        const uint32_t a = ldg<uint32_t>(rec, ((uint32_t)P.dyn0_off + sc) * 4u), b = ldg<uint32_t>(rec, ((uint32_t)P.dyn1_off + sc) * 4u);
+        const uint32_t a = ldrec<uint32_t>(dev, rec, ((uint32_t)P.dyn0_off + sc) * 4u), b = ldrec<uint32_t>(dev, rec, ((uint32_t)P.dyn1_off + sc) * 4u);
         e.d0[k] = (s < (uint32_t)cx.D) ? a : 0u;
         e.d1[k] = (s < (uint32_t)cx.D) ? b : 0u;
     }
@@ -112,10 +132,11 @@ __device__ __forceinline__ void load_env(const Params &P, Env<OPL, CPL, NA> &e, 
     e.agw = (lane < (uint32_t)NA) ? aw : 0u;
 }
 
-// header + agents in one 12-lane store (v_writelane assembles the words), cells / objects only when they changed
+// header + agents in one 12-lane store (v_writelane assembles the words), cells / objects only when they changed;
+// (`dev`: write-through stores, the next step of this env may run on another XCD before the next launch boundary, SEQ_*)
 template <int OPL, int CPL, int NA>
 __device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t *__restrict__ rec,
-                                          bool cells_dirty, bool objs_dirty, bool header_dirty = true) {
+                                          bool cells_dirty, bool objs_dirty, bool header_dirty = true, bool dev = false) {
     const uint32_t lane = (uint32_t)cx.lane;
     if (header_dirty) {
         uint32_t h = 0;
@@ -127,16 +148,16 @@ __device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL, N
         h = wrl(e.recipes, W_RECIPES, h);
         h = wrl(e.pool, W_POOL, h);
         h = wrl(e.marks_hi, W_MARKS_HI, h);
-        if (lane < (uint32_t)HDR_WORDS) stg<uint32_t>(rec, lane * 4u, h);
+        if (lane < (uint32_t)HDR_WORDS) strec<uint32_t>(dev, rec, lane * 4u, h);
     } else if (lane == 0u) {
-        stg<uint32_t>(rec, W_T * 4u, e.t);                          // the step counter is all that changed (the usual case)
+        strec<uint32_t>(dev, rec, W_T * 4u, e.t);                          // the step counter is all that changed (the usual case)
     }
-    if (lane < (uint32_t)MAX_AGENTS) stg<uint32_t>(rec, (AGENT_WORD0 + lane) * 4u, e.agw);
+    if (lane < (uint32_t)MAX_AGENTS) strec<uint32_t>(dev, rec, (AGENT_WORD0 + lane) * 4u, e.agw);
     if (cells_dirty) {
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
             const uint32_t c = lane + 64u * k;
-            if (c < (uint32_t)cx.C) stg<uint8_t>(rec, CELL_WORD0 * 4u + c, (uint8_t)e.cell[k]);
+            if (c < (uint32_t)cx.C) strec<uint8_t>(dev, rec, CELL_WORD0 * 4u + c, (uint8_t)e.cell[k]);
         }
     }
     if (objs_dirty) {
@@ -144,8 +165,8 @@ __device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL, N
         for (int k = 0; k < OPL; ++k) {
             const uint32_t s = lane + 64u * k;
             if (s < (uint32_t)cx.D) {
-                stg<uint32_t>(rec, ((uint32_t)P.dyn0_off + s) * 4u, e.d0[k]);
-                stg<uint32_t>(rec, ((uint32_t)P.dyn1_off + s) * 4u, e.d1[k]);
+                strec<uint32_t>(dev, rec, ((uint32_t)P.dyn0_off + s) * 4u, e.d0[k]);
+                strec<uint32_t>(dev, rec, ((uint32_t)P.dyn1_off + s) * 4u, e.d1[k]);
             }
         }
     }
@@ -470,15 +491,18 @@ struct Early {
     const int32_t *actions;        // Params::actions
     const double *lut;             // Params::lut
     int32_t N, RW, W, H, D, dyn0_off, dyn1_off;
+    uint32_t seq;                  // Params::seq (SEQ_* flags | launch number)
 };
 __host__ __device__ inline Early early_of(const Params &P) {
-    return Early{P.state, P.actions, P.lut, P.N, P.RW, P.W, P.H, P.D, P.dyn0_off, P.dyn1_off};
+    return Early{P.state, P.actions, P.lut, P.N, P.RW, P.W, P.H, P.D, P.dyn0_off, P.dyn1_off, P.seq};
 }
 
-template <int OPL, int CPL, int NA, int SCHEME, bool FUSED>
+// CHAIN = true: the one-step kernel of an overlapped run (SEQ_* in cz_device.h) -- its own instantiation, so that the
+// ordinary kernel's prologue stays free of branches (a branch in front of the loads costs 0.8 us per launch there)
+template <int OPL, int CPL, int NA, int SCHEME, bool FUSED, bool CHAIN = false>
 __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
                                                           int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
-                                                          int32_t e_dyn1, const Params P0) {
+                                                          int32_t e_dyn1, uint32_t e_seq, const Params P0) {
     Params P = P0;
     P.state = e_state; P.actions = e_actions; P.lut = e_lut; P.N = e_N; P.RW = e_RW; P.W = e_W; P.H = e_H; P.D = e_D;
     P.dyn0_off = e_dyn0; P.dyn1_off = e_dyn1;
@@ -500,12 +524,35 @@ __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_st
     CZ_STAMP(0);
     uint32_t *rec = P.state + (size_t)env * P.RW;
     double *retp = reinterpret_cast<double *>(rec + RET_WORD0);
+    // ---- an overlapped launch first waits for its env's predecessor (SEQ_* in cz_device.h); ordinary launches skip this
+    uint32_t *const seqw = P.state + (size_t)P.N * P.RW + (size_t)env * SEQ_STRIDE_WORDS;
+    static_assert(!(FUSED && CHAIN), "overlapped launches are one-step launches");
+    constexpr bool chained = CHAIN;
+    bool abandoned = false;
+    if (CHAIN && (e_seq & SEQ_WAIT) && env_raw < P.N) {
+        const uint32_t want = e_seq & SEQ_MASK;
+        uint32_t polls = 0;
+        uint64_t t_begin = 0;
+        while (rfl(ldg_dev<uint32_t>(seqw, 0)) != want) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++polls & 255u) == 0u) {                   // ~every 50 us: somebody else gave up, or two seconds have passed
+                const uint64_t now = wall_clock64();        // 100 MHz
+                if (t_begin == 0) t_begin = now;
+                uint32_t *const errw = CZ_LATE_STEP()->chain_err;
+                if (rfl(ldg_dev<uint32_t>(errw, 0)) != 0u || now - t_begin > 200000000ull) {
+                    if (lane == 0) __hip_atomic_store(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    abandoned = true;
+                    break;
+                }
+            }
+        }
+    }
     // ---- every load of the step is issued here, before anything waits
     int av = 0;
     if (!FUSED) av = ldg<int>(P.actions + (size_t)env * NA, (uint32_t)min(lane, NA - 1) * 4u);
-    double ret = ldg<double>(retp, ((uint32_t)lane & 3u) * 8u);                                           // running episode return, lane a = agent a
+    double ret = ldrec<double>(chained, retp, ((uint32_t)lane & 3u) * 8u);                                       // running episode return, lane a = agent a
     Env<OPL, CPL, NA> e;
-    load_env(P, e, cx, rec);
+    load_env(P, e, cx, rec, chained);
     init_lds<CPL>(P, cx, lds);
     uint32_t rowv = load_recipe_rows(P, e.recipes, lane);
     uint32_t dsc[OBS_CHUNK];
@@ -515,7 +562,7 @@ __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_st
     bool img_objs = true, img_cells = true;                 // which parts of the LDS image the next encode must rebuild
     if (threadIdx.x < (unsigned)LUT_SIZE) lut[threadIdx.x] = lutv;
     __syncthreads();
-    if (env_raw >= P.N) return;
+    if (env_raw >= P.N || (CHAIN && abandoned)) return;
     CZ_STAMP(1);
 
     const int T = FUSED ? P.T : 1;
@@ -556,13 +603,15 @@ __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_st
         if (o.finished) {
             uint32_t *su = kp->stat_u + (size_t)env * SU_WORDS;
             double *sf = kp->stat_f + (size_t)env * SF_WORDS;
+            // (read-modify-write across launches: device-scope loads, write-through stores, like the record)
+            const auto bump = [&](int word, uint32_t by) { strec<uint32_t>(chained, su, (uint32_t)word * 4u, ldrec<uint32_t>(chained, su, (uint32_t)word * 4u) + by); };
             if (lane == 0) {
-                su[SU_EPISODES] += 1; su[SU_LENSUM] += e.t; su[SU_TRUNC] += o.trunc; su[SU_TERM] += o.term;
+                bump(SU_EPISODES, 1u); bump(SU_LENSUM, e.t); bump(SU_TRUNC, (uint32_t)o.trunc); bump(SU_TERM, (uint32_t)o.term);
             }
             if (lane < NA) {
                 const uint32_t root = Pt.wide ? (((lane < 2 ? e.marks : e.marks_hi) >> (16 * (lane & 1))) & 1u) : ((e.marks >> (8 * lane)) & 1u);
-                su[SU_COMPLETED0 + lane] += root;
-                sf[SF_SUM0 + lane] += ret;
+                bump(SU_COMPLETED0 + lane, root);
+                strec<double>(chained, sf, (uint32_t)(SF_SUM0 + lane) * 8u, ldrec<double>(chained, sf, (uint32_t)(SF_SUM0 + lane) * 8u) + ret);
             }
             ret = 0.0;
         }
@@ -571,13 +620,14 @@ __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_st
         if (lane < NA) {
             double *const rewards = kp->rewards;
             uint8_t *const term = kp->term, *const trunc = kp->trunc;
-            if (rewards) stg<double>(rewards + row * NA, (uint32_t)lane * 8u, myrew);
-            if (term) stg<uint8_t>(term + row * NA, (uint32_t)lane, (uint8_t)o.term);
-            if (trunc) stg<uint8_t>(trunc + row * NA, (uint32_t)lane, (uint8_t)o.trunc);
+            // (write-through in an overlapped run: the next launch rewrites the same bytes, possibly from another XCD)
+            if (rewards) strec<double>(chained, rewards + row * NA, (uint32_t)lane * 8u, myrew);
+            if (term) strec<uint8_t>(chained, term + row * NA, (uint32_t)lane, (uint8_t)o.term);
+            if (trunc) strec<uint8_t>(chained, trunc + row * NA, (uint32_t)lane, (uint8_t)o.trunc);
         }
         if (!FUSED) {
             uint32_t *const marks_out = kp->marks_out;
-            if (marks_out && lane < 2) marks_out[2 * (size_t)env + lane] = lane == 0 ? e.marks : e.marks_hi;   // infos["recipe_done"] of the host API
+            if (marks_out && lane < 2) strec<uint32_t>(chained, marks_out + 2 * (size_t)env, (uint32_t)lane * 4u, lane == 0 ? e.marks : e.marks_hi);   // infos["recipe_done"] of the host API
         }
         CZ_STAMP(5);
         img_objs |= (dt.touched | dt.moved) != 0;
@@ -588,8 +638,15 @@ __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_st
         }
         CZ_STAMP(6);
     }
-    store_env(P, e, cx, rec, cells_dirty, objs_dirty, header_dirty);
-    if (lane < NA) stg<double>(retp, (uint32_t)lane * 8u, ret);
+    store_env(P, e, cx, rec, cells_dirty, objs_dirty, header_dirty, chained);
+    if (lane < NA) strec<double>(chained, retp, (uint32_t)lane * 8u, ret);
+    if (CHAIN) {
+        // Every store of this wave has been acknowledged at device scope before the successor may look.  (Handing the
+        // record over before the encode, with a second number that orders the observation stores of the two launches, was
+        // measured: 4.96 us per launch without that second wait, 7.95 us with it, against 5.15 us for this form.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) stg_wt<uint32_t>(seqw, 0, ((e_seq & SEQ_MASK) + 1u) & SEQ_MASK);
+    }
     CZ_STAMP(7);
 }
 
@@ -655,9 +712,12 @@ struct Inst {
         constexpr int EPW = envs_per_wg<CPL>();
         const dim3 grid((unsigned)((P.N + EPW - 1) / EPW)), block(64 * EPW);
         const Early E = early_of(P);
-#define CZ_LAUNCH_STEP(S, F) \
-    hipLaunchKernelGGL((k_step<OPL, CPL, NA, S, F>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, P)
-        if (P.actions) {
+#define CZ_LAUNCH_STEP(S, F, ...) \
+    hipLaunchKernelGGL((k_step<OPL, CPL, NA, S, F, ##__VA_ARGS__>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, E.seq, P)
+        if (P.actions && (P.seq & SEQ_PUBLISH)) {
+            if (P.scheme == 3) CZ_LAUNCH_STEP(3, false, true);
+            else CZ_LAUNCH_STEP(1, false, true);
+        } else if (P.actions) {
             if (P.scheme == 3) CZ_LAUNCH_STEP(3, false);
             else CZ_LAUNCH_STEP(1, false);
         } else {

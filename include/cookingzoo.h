@@ -152,6 +152,14 @@ int cz_ring_prepare(cz_handle h, int32_t K, const int32_t *d_ring, int64_t actio
  * (reset != 0: zero both after reading).  bench.py describes its run from these numbers. */
 int cz_launch_counts(cz_handle h, int64_t *graph_kernels, int64_t *direct_kernels, int32_t reset);
 
+/* Runs of two or more steps whose observation stores are write-through (batches up to 128 MiB of observations per step)
+ * go out as OVERLAPPED launches unless CZ_CHAIN=0: consecutive step kernels alternate between the handle's stream and an
+ * internal one, and every env's step waits for that env's previous step (a sequence word per env) instead of for the
+ * whole previous kernel, so the launch boundary hides behind the neighbouring kernel's work.  Same results, same order
+ * per env; later work on the handle's stream waits for the whole run.  This reports how many kernels went out that way
+ * (reset != 0: zero after reading).  cz_sync fails if a hand-off ever timed out. */
+int cz_chain_counts(cz_handle h, int64_t *chained_kernels, int32_t reset);
+
 /* T fused steps in one launch with on-device uniform random actions (counter-based stream keyed by
  * (seed, global env id, agent, step0 + t)); state stays in registers between steps.  d_obs, if not NULL,
  * is a trajectory buffer [T][N][A][F]; d_rewards [T][N][A]; d_term/d_trunc [T][N][A] (each may be NULL

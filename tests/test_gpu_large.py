@@ -87,6 +87,67 @@ def test_both_store_flavours_match_oracle(wt, level, meta, agents, recipes, sche
     env.close()
 
 
+def _ring_run_vs_oracle(env, orc, K, period, rng, first_slot=0):
+    """K steps through cz_step_device_ring (overlapped launches when the batch qualifies) against the oracle: what the last
+    step left in the output buffers, the records, the episode statistics."""
+    import ctypes as C
+    from cooking_zoo_amd import _native
+    n, A = env.num_envs, env.num_agents
+    L = _native.lib()
+    ring_host = rng.integers(0, env.n_actions, size=(period, n, A), dtype=np.int32)
+    d_ring = env.alloc((period, n, A), np.int32)
+    d_ring.from_host(ring_host)
+    d_obs = env.alloc((n, A, env.F), np.float64)
+    d_rew = env.alloc((n, A), np.float64)
+    d_t = env.alloc((n, A), np.uint8)
+    d_u = env.alloc((n, A), np.uint8)
+    _native.check(env._h, L.cz_step_device_ring(env._h, K, d_ring.ptr, n * A, period, first_slot, d_obs.ptr, d_rew.ptr, d_t.ptr, d_u.ptr))
+    env.sync()
+    for k in range(K):
+        oo, ro, to, uo = orc.step(ring_host[(first_slot + k) % period], k == K - 1)
+    assert np.array_equal(strip(env.get_state()), orc.records), "records after the run"
+    assert np.array_equal(bits(d_obs.to_host()), bits(oo)), "observation of the last step"
+    assert np.array_equal(bits(d_rew.to_host()), bits(ro)), "rewards of the last step"
+    assert np.array_equal(d_t.to_host(), to) and np.array_equal(d_u.to_host(), uo), "flags of the last step"
+    for b in (d_ring, d_obs, d_rew, d_t, d_u):
+        b.free()
+
+
+@pytest.mark.parametrize("level,meta,agents,recipes,scheme", FAMILIES)
+def test_overlapped_runs_match_oracle(level, meta, agents, recipes, scheme):
+    """Runs of cz_step_device_ring go out as overlapped launches (two streams alternately, a sequence word per env instead
+    of the launch boundary): same results as stepping the oracle one step at a time, for every level family, with
+    episodes ending and restarting inside the runs; and the library says that it did overlap."""
+    import ctypes as C
+    from cooking_zoo_amd import _native
+    from oracle_binding import VecOracle
+    env = make(200, level, meta, agents, recipes, scheme, max_steps=17, num_layouts=6)
+    orc = VecOracle.from_vec_env(env)
+    assert np.array_equal(bits(env.reset()), bits(orc.reset()))
+    rng = np.random.default_rng(5)
+    L = _native.lib()
+    L.cz_chain_counts(env._h, None, 1)
+    for K, period, first in ((2, 8, 0), (37, 16, 5), (3, 3, 2), (60, 64, 63)):
+        _ring_run_vs_oracle(env, orc, K, period, rng, first)
+    c = C.c_int64()
+    L.cz_chain_counts(env._h, C.byref(c), 0)
+    assert c.value == 2 + 37 + 3 + 60
+    st = env.stats()
+    assert st["episodes"] == int(orc.records[:, soa.W_EPISODE].sum()) + int((orc.records[:, soa.W_STATUS] & 1).sum())
+    env.close()
+
+
+def test_overlapped_run_16384_envs_300_steps():
+    """the largest config-2 batch that still qualifies (73 MB of observations per step), a long run: 4.9 M env-steps in
+    300 overlapped launches, episodes of at most 40 steps"""
+    from oracle_binding import ShardedOracle
+    env = make(16384, "coop_test", "example", 2, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3", max_steps=40, num_layouts=64)
+    orc = ShardedOracle(env)
+    assert np.array_equal(bits(env.reset()), bits(orc.reset()))
+    _ring_run_vs_oracle(env, orc, 300, 32, np.random.default_rng(77))
+    env.close()
+
+
 def _full_size_case(env, steps, T_fused, seed):
     """`steps` one-launch-per-step launches with external actions (every output compared at every step), then one fused
     rollout of T_fused steps (final records, last observation, last rewards / flags compared)."""
