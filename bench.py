@@ -267,6 +267,17 @@ def worker(args):
     run_steps(n_ev, 0)                                         # the ring end to end, as few replays as possible
     L.cz_timer_stop(h, C.byref(ev_ms))                         # event after the last launch, synchronised
     kernel_us = [ev_ms.value * 1e3 / n_ev]
+    # the same launches ordered by launch boundaries only (overlap switched off for this pass): the duration of one kernel
+    # when nothing runs beside it, which is what a per-kernel trace of such a run shows
+    was = L.cz_set_overlap(h, 0)
+    _native.check(h, L.cz_ring_prepare(h, n_ev, *ring, 0, *outs))
+    barrier()
+    L.cz_timer_start(h)
+    run_steps(n_ev, 0)
+    L.cz_timer_stop(h, C.byref(ev_ms))
+    kernel_us.append(ev_ms.value * 1e3 / n_ev)
+    L.cz_set_overlap(h, was)
+    overlapped = bool(c_k.value)
     mine = {"elapsed_s": elapsed, "env_steps": steps_done, "kernel_us": kernel_us, "stats": env.stats()}
     every = [json.loads(b) for b in rdzv.all_gather(json.dumps(mine).encode())]
 
@@ -351,8 +362,16 @@ def worker(args):
                        "api": api},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(f"k_step_{N}"),
-                         "kernel": "cz::k_step<1,1,2,3,false> (one wavefront per env, 8 envs per workgroup)",
-                         "kernel_us": kernel_med, "kernel_us_from": f"HIP events around {max(R * K, 4000)} back-to-back launches on the kernels' stream",
+                         "kernel": ("cz::k_step<1,1,2,3,false,true>" if overlapped else "cz::k_step<1,1,2,3,false>") +
+                                   " (one wavefront per env, 8 envs per workgroup)",
+                         "kernel_us": kernel_med,
+                         "kernel_us_from": (f"HIP events on the kernels' stream around {max(R * K, 4000)} launches issued back to back, "
+                                            f"divided by the number of launches" +
+                                            ("; the launches OVERLAP pairwise (two streams alternately, per-env sequence words), so "
+                                             "this is the launch-to-launch interval: a per-kernel trace shows each kernel resident for "
+                                             "about twice as long, two at a time" if overlapped else "")),
+                         "kernel_us_boundary_ordered": kernel_us[1],
+                         "frac_boundary_ordered": b_alg * N / (kernel_us[1] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "alg_bytes_per_env_step": b_alg, "units_per_launch": N,
                          # measured on this box, same run: a kernel of the same grid shape that ONLY writes the observation
                          # bytes (write-through 16-byte stores); write-only traffic does not reach the 8 TB/s read+write peak

@@ -59,6 +59,8 @@ SYMBOLS = [
     ("cz_ring_prepare", C.c_int, [_VP, _I32, _VP, _I64, _I32, _I32, _VP, _VP, _VP, _VP]),
     ("cz_launch_counts", C.c_int, [_VP, C.POINTER(_I64), C.POINTER(_I64), _I32]),
     ("cz_chain_counts", C.c_int, [_VP, C.POINTER(_I64), _I32]),
+    ("cz_set_overlap", C.c_int, [_VP, _I32]),
+    ("cz_overlap_limit", _I64, [_VP]),
     ("cz_last_marks", C.c_int, [_VP, _VP]),
     ("cz_set_stream", C.c_int, [_VP, _VP]),
     ("cz_probe_output_only", C.c_int, [_VP, _VP, C.c_size_t, _I32, _VP]),

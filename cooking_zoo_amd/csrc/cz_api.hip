@@ -127,8 +127,9 @@ struct cz_handle_s {
     hipStream_t own_stream = nullptr;  // the one cz_create made (cz_set_stream may point `stream` at a caller's)
     // overlapped ("chained") runs of cz_step_device_ring: odd steps go to aux_stream (SEQ_* in cz_device.h)
     hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr;
     bool chain_enabled = true;         // CZ_CHAIN=0: runs are ordered by launch boundaries only (graph replay)
+    int64_t chain_max_envs = 0;        // largest batch that may overlap (2/3 of the waves the device holds, see cz_create)
     uint32_t seq_counter = 0;          // number of the next chained launch (mod 2^30)
     uint32_t *h_chain_err = nullptr;   // pinned, device-mapped: set by a wave whose hand-off never came
     int64_t n_chained_kernels = 0;
@@ -254,7 +255,6 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     h->stream = h->own_stream;
     CREATE_CHK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
     CREATE_CHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    CREATE_CHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     CREATE_CHK(hipHostMalloc((void **)&h->h_chain_err, 64, hipHostMallocMapped));
     *h->h_chain_err = 0;
     CREATE_CHK(hipEventCreate(&h->ev0));
@@ -280,6 +280,17 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // honoured by the diagnostic build only
     h->kl = (P.D <= 64 && C <= 64) ? launchers_small() : (P.D <= 128 && C <= 256) ? launchers_large() : launchers_huge();
     h->huge = P.D > 128 || C > 256;
+    {   // Overlapped launches: a kernel's waves spin until their predecessors, waves of the previous kernel, have run.  A
+        // wave that waits for a workgroup which cannot be dispatched because the waiting waves hold every slot would wait
+        // forever; so the waiting kernel (N waves at most) must never be able to fill the device: N <= 2/3 of the waves the
+        // device holds of this kernel leaves the predecessor a third of the slots at the very least (its workgroups were
+        // queued first, and at most two of these kernels are in flight: the third waits for the first on its stream).
+        hipDeviceProp_t prop;
+        CREATE_CHK(hipGetDeviceProperties(&prop, cfg->device_id));
+        int64_t resident = 0;
+        CREATE_CHK(h->kl.resident_envs(P, prop.multiProcessorCount, &resident));
+        h->chain_max_envs = resident * 2 / 3;
+    }
     {   // the reward of a step on which no recipe node changed: cooking_env.py:304-307 with zero deltas, same op order
         double x = 0.0;
         x += (double)0 * P.node_reward;
@@ -350,7 +361,6 @@ extern "C" int cz_destroy(cz_handle h) {
     if (h->h_marks) (void)hipHostFree(h->h_marks);
     if (h->h_chain_err) (void)hipHostFree(h->h_chain_err);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     for (hipEvent_t e : h->kev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -584,24 +594,34 @@ static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr) {
 // can this launch be part of an overlapped run?  (one-step kernel with write-through observation stores: two waves of
 // different launches write the same output bytes, so those must not sit dirty in two L2s)
 static bool chainable(cz_handle h, const Params &P) {
-    if (!h->chain_enabled || h->ktime || !P.actions) return false;
+    if (!h->chain_enabled || h->ktime || !P.actions || P.N > h->chain_max_envs) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;   // a caller's capture
     if (h->wt_override >= 0) return h->wt_override == 1;
     return (size_t)P.N * P.A * P.F * 8 <= ((size_t)128 << 20);
 }
-// K steps of an overlapped run: even steps on the handle's stream, odd steps on aux_stream, every launch but the first
-// waits per env for its predecessor's sequence number (cz_kernels.h k_step) instead of for the whole previous kernel
+// K steps of an overlapped run on the handle's stream and aux_stream alternately; every launch but the first waits per
+// env for its predecessor's sequence number (cz_kernels.h k_step) instead of for the whole previous kernel.
+// * The first and the LAST launch go to the handle's stream.  The first is thereby ordered after whatever the caller queued
+//   before the run, and everything else follows from it env by env.  When the last one has completed, every env has gone
+//   through every step, and a wave publishes its number only after its stores were acknowledged - so later work on the
+//   handle's stream (or a synchronisation of it) needs no join with aux_stream.
+// * aux_stream's kernels would otherwise only spin until the first launch gets to run; if the caller's stream is still busy
+//   that could outlast the spin deadline, so in that case (only) aux_stream first waits for the stream's current tail.
 static int launch_chain(cz_handle h, Params &P, int32_t K, const int32_t *d_ring, int64_t stride, int32_t period, int32_t first_slot) {
-    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+    if (hipStreamQuery(h->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+    }
     for (int32_t k = 0; k < K; ++k) {
         P.actions = d_ring + (int64_t)(((int64_t)first_slot + k) % period) * stride;
         P.seq = SEQ_PUBLISH | (k > 0 ? SEQ_WAIT : 0u) | ((h->seq_counter + (uint32_t)k) & SEQ_MASK);
-        if (launch_step(h, P, (k & 1) ? h->aux_stream : h->stream)) return 1;
+        const bool on_main = k == 0 || ((K - 1 - k) & 1) == 0;
+        if (launch_step(h, P, on_main ? h->stream : h->aux_stream)) return 1;
     }
     P.seq = 0;
     h->seq_counter = (h->seq_counter + (uint32_t)K) & SEQ_MASK;
-    HIPCHK(h, hipEventRecord(h->ev_join, h->aux_stream));
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     h->n_chained_kernels += K;
     return 0;
 }
@@ -814,6 +834,15 @@ extern "C" int cz_step_device_ring(cz_handle h, int32_t K, const int32_t *d_ring
     if (!d_ring || K < 1 || period < 1 || first_slot < 0 || first_slot >= period) return fail(h, "cz_step_device_ring: bad arguments");
     if (set_device(h)) return 1;
     return ring_walk(h, K, d_ring, stride, period, first_slot, d_obs, d_rewards, d_term, d_trunc, true);
+}
+// the largest batch (envs of this handle's kernel) that two overlapped launches fit the device with; larger batches never overlap
+extern "C" int64_t cz_overlap_limit(cz_handle h) { return h ? h->chain_max_envs : 0; }
+// overlapped launches on / off for this handle (default: on unless CZ_CHAIN=0); returns the previous setting
+extern "C" int cz_set_overlap(cz_handle h, int32_t enabled) {
+    if (!h) return fail(nullptr, "null handle");
+    const int was = h->chain_enabled ? 1 : 0;
+    h->chain_enabled = enabled != 0;
+    return was;
 }
 // how many step kernels of this handle went out as overlapped launches (cz_step_device_ring only); reset != 0 zeroes it
 extern "C" int cz_chain_counts(cz_handle h, int64_t *chained_kernels, int32_t reset) {

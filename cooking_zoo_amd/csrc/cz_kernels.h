@@ -703,10 +703,30 @@ struct Launchers {
     hipError_t (*step)(const Params &, hipStream_t);
     hipError_t (*reset)(const Params &, hipStream_t, int64_t, int, const int32_t *, const uint32_t *, const uint32_t *, double *);
     hipError_t (*observe)(const Params &, hipStream_t, int64_t, int, double *);
+    // how many envs of the overlapped one-step kernel (P.A agents, P.scheme) can be resident on the device at once
+    hipError_t (*resident_envs)(const Params &, int num_cus, int64_t *envs);
 };
 
 template <int OPL, int CPL>
 struct Inst {
+    template <int NA>
+    static hipError_t resident_na(const Params &P, int num_cus, int64_t *envs) {
+        constexpr int EPW = envs_per_wg<CPL>();
+        int per_cu = 0;
+        hipError_t e;
+        if (P.scheme == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step<OPL, CPL, NA, 3, false, true>, 64 * EPW, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step<OPL, CPL, NA, 1, false, true>, 64 * EPW, 0);
+        *envs = (int64_t)per_cu * num_cus * EPW;
+        return e;
+    }
+    static hipError_t resident_envs(const Params &P, int num_cus, int64_t *envs) {
+        switch (P.A) {
+        case 1: return resident_na<1>(P, num_cus, envs);
+        case 2: return resident_na<2>(P, num_cus, envs);
+        case 3: return resident_na<3>(P, num_cus, envs);
+        default: return resident_na<4>(P, num_cus, envs);
+        }
+    }
     template <int NA>
     static hipError_t step_na(const Params &P, hipStream_t st) {
         constexpr int EPW = envs_per_wg<CPL>();

@@ -159,6 +159,12 @@ int cz_launch_counts(cz_handle h, int64_t *graph_kernels, int64_t *direct_kernel
  * per env; later work on the handle's stream waits for the whole run.  This reports how many kernels went out that way
  * (reset != 0: zero after reading).  cz_sync fails if a hand-off ever timed out. */
 int cz_chain_counts(cz_handle h, int64_t *chained_kernels, int32_t reset);
+/* Switch overlapped launches on (default, unless CZ_CHAIN=0) or off for this handle; returns the previous setting (0 / 1). */
+int cz_set_overlap(cz_handle h, int32_t enabled);
+/* A kernel whose waves wait for their predecessors must never be able to fill the device (a waiting wave would hold the
+ * slot its predecessor needs): batches above 2/3 of the waves the device holds of this kernel are never overlapped.
+ * 4096 envs for the 7x7 levels on an MI355X. */
+int64_t cz_overlap_limit(cz_handle h);
 
 /* T fused steps in one launch with on-device uniform random actions (counter-based stream keyed by
  * (seed, global env id, agent, step0 + t)); state stays in registers between steps.  d_obs, if not NULL,

@@ -71,6 +71,21 @@ def test_random_configuration_matches_oracle(i):
         assert np.array_equal(bits(o), bits(oo)) and np.array_equal(bits(r), bits(ro)), (ctx, t)
         assert np.array_equal(te, to) and np.array_equal(tr, uo), (ctx, t)
     assert np.array_equal(strip(env.get_state()), orc.records), ctx
+    # ... and a run of overlapped launches (cz_step_device_ring: the third kernel variant, ordered per env by sequence words)
+    from cooking_zoo_amd import _native
+    K, period = int(rng.integers(2, 40)), int(rng.integers(2, 12))
+    first = int(rng.integers(period))
+    ring_host = rng.integers(0, n_act, size=(period, n, A), dtype=np.int32)
+    d_ring, d_obs = env.alloc((period, n, A), np.int32), env.alloc((n, A, env.F), np.float64)
+    d_ring.from_host(ring_host)
+    _native.check(env._h, _native.lib().cz_step_device_ring(env._h, K, d_ring.ptr, n * A, period, first, d_obs.ptr, d_rew.ptr,
+                                                            d_term.ptr, d_trunc.ptr))
+    env.sync()
+    for k in range(K):
+        oo, ro, to, uo = orc.step(ring_host[(first + k) % period], k == K - 1)
+    assert np.array_equal(strip(env.get_state()), orc.records), ctx
+    assert np.array_equal(bits(d_obs.to_host()), bits(oo)) and np.array_equal(bits(d_rew.to_host()[0]), bits(ro)), ctx
+    assert np.array_equal(d_term.to_host()[0], to) and np.array_equal(d_trunc.to_host()[0], uo), ctx
     st = env.stats()
     assert st["episodes"] == int(orc.records[:, soa.W_EPISODE].sum()) + int((orc.records[:, soa.W_STATUS] & 1).sum()), ctx
     env.close()

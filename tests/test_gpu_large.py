@@ -137,14 +137,24 @@ def test_overlapped_runs_match_oracle(level, meta, agents, recipes, scheme):
     env.close()
 
 
-def test_overlapped_run_16384_envs_300_steps():
-    """the largest config-2 batch that still qualifies (73 MB of observations per step), a long run: 4.9 M env-steps in
-    300 overlapped launches, episodes of at most 40 steps"""
+@pytest.mark.parametrize("n,overlaps", [(4096, True), (16384, False)])
+def test_long_ring_runs_at_and_above_the_overlap_limit(n, overlaps):
+    """300-step runs of the config-2 workload.  4096 envs: a kernel's waiting waves leave at least a third of the device
+    to its predecessor, so the run goes out as overlapped launches.  16 384 envs: the waiting waves could hold every slot
+    their predecessors still need, so the library must not overlap (it replays graphs) - and says so."""
+    import ctypes as C
+    from cooking_zoo_amd import _native
     from oracle_binding import ShardedOracle
-    env = make(16384, "coop_test", "example", 2, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3", max_steps=40, num_layouts=64)
+    env = make(n, "coop_test", "example", 2, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3", max_steps=40, num_layouts=64)
     orc = ShardedOracle(env)
     assert np.array_equal(bits(env.reset()), bits(orc.reset()))
+    L = _native.lib()
+    assert (n <= L.cz_overlap_limit(env._h)) == overlaps
+    L.cz_chain_counts(env._h, None, 1)
     _ring_run_vs_oracle(env, orc, 300, 32, np.random.default_rng(77))
+    c = C.c_int64()
+    L.cz_chain_counts(env._h, C.byref(c), 0)
+    assert c.value == (300 if overlaps else 0)
     env.close()
 
 
