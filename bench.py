@@ -200,6 +200,10 @@ def worker(args):
                         device_id=local_rank, env_id_base=begin)
     L, h = _native.lib(), env._h
     env.reset(return_obs=False)
+    # this process drives one handle on its GPU: runs of step launches may overlap (cz_set_overlap in include/cookingzoo.h;
+    # CZ_CHAIN=0 keeps the launch-boundary ordering with graph replay)
+    if os.environ.get("CZ_CHAIN", "1") != "0":
+        env.set_overlap(True)
 
     # inputs resident in HBM: a ring of int32 [N, A] action tensors, one slot per step (uniform over the 5 scheme3
     # actions); outputs: obs f64 [N, A, F], rewards f64, terminations / truncations u8.  The ring holds a whole number of
@@ -269,7 +273,7 @@ def worker(args):
     kernel_us = [ev_ms.value * 1e3 / n_ev]
     # the same launches ordered by launch boundaries only (overlap switched off for this pass): the duration of one kernel
     # when nothing runs beside it, which is what a per-kernel trace of such a run shows
-    was = L.cz_set_overlap(h, 0)
+    was = max(L.cz_set_overlap(h, 0), 0)
     _native.check(h, L.cz_ring_prepare(h, n_ev, *ring, 0, *outs))
     barrier()
     L.cz_timer_start(h)

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -128,11 +129,12 @@ struct cz_handle_s {
     // overlapped ("chained") runs of cz_step_device_ring: odd steps go to aux_stream (SEQ_* in cz_device.h)
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr;
-    bool chain_enabled = true;         // CZ_CHAIN=0: runs are ordered by launch boundaries only (graph replay)
+    bool chain_enabled = false;        // cz_set_overlap / CZ_CHAIN=1; off: runs are ordered by launch boundaries only (graph replay)
     int64_t chain_max_envs = 0;        // largest batch that may overlap (2/3 of the waves the device holds, see cz_create)
     uint32_t seq_counter = 0;          // number of the next chained launch (mod 2^30)
     uint32_t *h_chain_err = nullptr;   // pinned, device-mapped: set by a wave whose hand-off never came
     int64_t n_chained_kernels = 0;
+    bool chain_wanted_by_env = false;
     Launchers kl;
     int n_layouts = 0, n_recipes = 0;
     uint32_t *d_state = nullptr, *d_lay_init = nullptr, *d_lay_desc = nullptr, *d_recipes = nullptr;
@@ -274,7 +276,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     P.stop = -1;
     if (const char *s = getenv("CZ_WT")) h->wt_override = atoi(s);
     if (const char *s = getenv("CZ_GRAPHS")) h->graphs_enabled = atoi(s) != 0;
-    if (const char *s = getenv("CZ_CHAIN")) h->chain_enabled = atoi(s) != 0;
+    h->chain_wanted_by_env = getenv("CZ_CHAIN") && atoi(getenv("CZ_CHAIN")) != 0;
     if (const char *s = getenv("CZ_RING_PREFIX")) h->ring_prefix = atoi(s) < 0 ? 0 : (atoi(s) > 16 ? 16 : atoi(s));
     if (const char *s = getenv("CZ_ZERO_COPY_BYTES")) h->zero_copy_bytes = (size_t)atoll(s);
     if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // honoured by the diagnostic build only
@@ -336,6 +338,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
             }
     }
 #undef CREATE_CHK
+    if (h->chain_wanted_by_env) (void)cz_set_overlap(h, 1);       // (stays off if another handle of the device has it)
     *out = h;
     return 0;
 }
@@ -345,6 +348,7 @@ extern "C" int cz_destroy(cz_handle h) {
     (void)hipSetDevice(h->cfg.device_id);
     (void)hipStreamSynchronize(h->stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+    if (h->chain_enabled) (void)cz_set_overlap(h, 0);
     if (h->comm && h->rccl) {
         typedef int (*destroy_t)(void *);
         destroy_t f = (destroy_t)dlsym(h->rccl, "ncclCommDestroy");
@@ -837,11 +841,27 @@ extern "C" int cz_step_device_ring(cz_handle h, int32_t K, const int32_t *d_ring
 }
 // the largest batch (envs of this handle's kernel) that two overlapped launches fit the device with; larger batches never overlap
 extern "C" int64_t cz_overlap_limit(cz_handle h) { return h ? h->chain_max_envs : 0; }
-// overlapped launches on / off for this handle (default: on unless CZ_CHAIN=0); returns the previous setting
+// Overlapped launches on / off for this handle (off by default; CZ_CHAIN=1 switches them on at cz_create when no other
+// handle of the device has them).  One handle per device and process: the waiting kernels of two handles together could
+// fill the device, which is what cz_overlap_limit rules out for one.  Returns the previous setting, or -1 (see
+// cz_last_error) when another handle of this device holds the right.
+static std::atomic<cz_handle> g_overlap_owner[64];
 extern "C" int cz_set_overlap(cz_handle h, int32_t enabled) {
-    if (!h) return fail(nullptr, "null handle");
+    if (!h) { fail(nullptr, "null handle"); return -1; }
     const int was = h->chain_enabled ? 1 : 0;
-    h->chain_enabled = enabled != 0;
+    std::atomic<cz_handle> &owner = g_overlap_owner[h->cfg.device_id & 63];
+    if (enabled && !was) {
+        cz_handle none = nullptr;
+        if (!owner.compare_exchange_strong(none, h)) {
+            fail(h, "cz_set_overlap: another handle of device %d already overlaps its runs (one per device and process)", h->cfg.device_id);
+            return -1;
+        }
+        h->chain_enabled = true;
+    } else if (!enabled && was) {
+        h->chain_enabled = false;
+        cz_handle me = h;
+        owner.compare_exchange_strong(me, nullptr);
+    }
     return was;
 }
 // how many step kernels of this handle went out as overlapped launches (cz_step_device_ring only); reset != 0 zeroes it

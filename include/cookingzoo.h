@@ -152,19 +152,24 @@ int cz_ring_prepare(cz_handle h, int32_t K, const int32_t *d_ring, int64_t actio
  * (reset != 0: zero both after reading).  bench.py describes its run from these numbers. */
 int cz_launch_counts(cz_handle h, int64_t *graph_kernels, int64_t *direct_kernels, int32_t reset);
 
-/* Runs of two or more steps whose observation stores are write-through (batches up to 128 MiB of observations per step)
- * go out as OVERLAPPED launches unless CZ_CHAIN=0: consecutive step kernels alternate between the handle's stream and an
- * internal one, and every env's step waits for that env's previous step (a sequence word per env) instead of for the
- * whole previous kernel, so the launch boundary hides behind the neighbouring kernel's work.  Same results, same order
- * per env; later work on the handle's stream waits for the whole run.  This reports how many kernels went out that way
- * (reset != 0: zero after reading).  cz_sync fails if a hand-off ever timed out. */
-int cz_chain_counts(cz_handle h, int64_t *chained_kernels, int32_t reset);
-/* Switch overlapped launches on (default, unless CZ_CHAIN=0) or off for this handle; returns the previous setting (0 / 1). */
+/* OVERLAPPED LAUNCHES (opt-in).  With cz_set_overlap(h, 1), runs of two or more steps of cz_step_device_ring go out with
+ * consecutive step kernels alternating between the handle's stream and an internal one; every env's step waits for that
+ * env's previous step (a sequence word per env, device-scope loads and write-through stores) instead of for the whole
+ * previous kernel, so the launch boundary hides behind the neighbouring kernel's work (5.2 instead of 6.2 us per step at
+ * 4096 envs).  Same results, same order per env; the first and the last launch of a run are on the handle's stream, so
+ * later work on it (or cz_sync) sees the whole run.
+ *   - Only batches of at most cz_overlap_limit(h) envs overlap (a kernel whose waves wait for their predecessors must
+ *     never be able to fill the device: 2/3 of the waves the device holds of this kernel; 4096 envs for the 7x7 levels
+ *     on an MI355X), only while the observation stores are write-through (up to 128 MiB of observations per step), and
+ *     never inside a stream capture of the caller.  Everything else is replayed from graphs as before.
+ *   - One handle per device and process may have it switched on (cz_set_overlap returns -1 for a second one): the
+ *     waiting kernels of two handles together could fill the device.  CZ_CHAIN=1 switches it on at cz_create.
+ *   - A hand-off that does not arrive within two seconds marks the handle (cz_sync then fails) instead of hanging.
+ * cz_set_overlap returns the previous setting (0 / 1) or -1; cz_chain_counts reports how many kernels went out
+ * overlapped (reset != 0: zero after reading). */
 int cz_set_overlap(cz_handle h, int32_t enabled);
-/* A kernel whose waves wait for their predecessors must never be able to fill the device (a waiting wave would hold the
- * slot its predecessor needs): batches above 2/3 of the waves the device holds of this kernel are never overlapped.
- * 4096 envs for the 7x7 levels on an MI355X. */
 int64_t cz_overlap_limit(cz_handle h);
+int cz_chain_counts(cz_handle h, int64_t *chained_kernels, int32_t reset);
 
 /* T fused steps in one launch with on-device uniform random actions (counter-based stream keyed by
  * (seed, global env id, agent, step0 + t)); state stays in registers between steps.  d_obs, if not NULL,

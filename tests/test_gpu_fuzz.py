@@ -73,6 +73,7 @@ def test_random_configuration_matches_oracle(i):
     assert np.array_equal(strip(env.get_state()), orc.records), ctx
     # ... and a run of overlapped launches (cz_step_device_ring: the third kernel variant, ordered per env by sequence words)
     from cooking_zoo_amd import _native
+    env.set_overlap(True)
     K, period = int(rng.integers(2, 40)), int(rng.integers(2, 12))
     first = int(rng.integers(period))
     ring_host = rng.integers(0, n_act, size=(period, n, A), dtype=np.int32)

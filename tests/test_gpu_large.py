@@ -122,6 +122,7 @@ def test_overlapped_runs_match_oracle(level, meta, agents, recipes, scheme):
     from cooking_zoo_amd import _native
     from oracle_binding import VecOracle
     env = make(200, level, meta, agents, recipes, scheme, max_steps=17, num_layouts=6)
+    env.set_overlap(True)
     orc = VecOracle.from_vec_env(env)
     assert np.array_equal(bits(env.reset()), bits(orc.reset()))
     rng = np.random.default_rng(5)
@@ -146,6 +147,7 @@ def test_long_ring_runs_at_and_above_the_overlap_limit(n, overlaps):
     from cooking_zoo_amd import _native
     from oracle_binding import ShardedOracle
     env = make(n, "coop_test", "example", 2, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3", max_steps=40, num_layouts=64)
+    env.set_overlap(True)
     orc = ShardedOracle(env)
     assert np.array_equal(bits(env.reset()), bits(orc.reset()))
     L = _native.lib()
@@ -156,6 +158,29 @@ def test_long_ring_runs_at_and_above_the_overlap_limit(n, overlaps):
     L.cz_chain_counts(env._h, C.byref(c), 0)
     assert c.value == (300 if overlaps else 0)
     env.close()
+
+
+def test_overlap_is_opt_in_and_one_handle_per_device():
+    import ctypes as C
+    from cooking_zoo_amd import _native
+    from oracle_binding import VecOracle
+    a = make(64, "coop_test", "example", 2, ["TomatoLettuceSalad", "CarrotBanana"])
+    b = make(64, "coop_test", "example", 2, ["TomatoLettuceSalad", "CarrotBanana"])
+    orc = VecOracle.from_vec_env(a)
+    assert np.array_equal(bits(a.reset()), bits(orc.reset()))
+    L, c = _native.lib(), C.c_int64()
+    _ring_run_vs_oracle(a, orc, 10, 4, np.random.default_rng(1))           # off by default: graph replay
+    L.cz_chain_counts(a._h, C.byref(c), 1)
+    assert c.value == 0
+    assert a.set_overlap(True) is False and a.set_overlap(True) is True      # returns the previous setting
+    with pytest.raises(_native.NativeError, match="another handle"):
+        b.set_overlap(True)
+    _ring_run_vs_oracle(a, orc, 10, 4, np.random.default_rng(2))
+    L.cz_chain_counts(a._h, C.byref(c), 1)
+    assert c.value == 10
+    a.close()                                                                 # releases the right
+    assert b.set_overlap(True) is False
+    b.close()
 
 
 def _full_size_case(env, steps, T_fused, seed):
