@@ -366,7 +366,7 @@ def worker(args):
                        "api": api},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(f"k_step_{N}"),
-                         "kernel": ("cz::k_step<1,1,2,3,false,true>" if overlapped else "cz::k_step<1,1,2,3,false>") +
+                         "kernel": ("cz::k_step_chain<1,1,2,3>" if overlapped else "cz::k_step<1,1,2,3,false>") +
                                    " (one wavefront per env, 8 envs per workgroup)",
                          "kernel_us": kernel_med,
                          "kernel_us_from": (f"HIP events on the kernels' stream around {max(R * K, 4000)} launches issued back to back, "

@@ -208,7 +208,12 @@ extern "C" int32_t cz_abi_version(void) { return 3; }
 // diagnostic builds only (tools/phase_profile.py): where the kernels write their s_memtime stamps
 extern "C" int cz_debug_set_stamps(cz_handle h, void *d_buf) {
     if (!h) return 1;
+#ifdef CZ_PROFILE
     h->P.stamps = (unsigned long long *)d_buf;
+#else
+    (void)d_buf;
+    return fail(h, "cz_debug_set_stamps: this is not the diagnostic build (make prof)");
+#endif
     return 0;
 }
 extern "C" int32_t cz_sizeof_config(void) { return (int32_t)sizeof(cz_config); }
@@ -255,10 +260,6 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     CREATE_CHK(hipSetDevice(cfg->device_id));
     CREATE_CHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
-    CREATE_CHK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-    CREATE_CHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    CREATE_CHK(hipHostMalloc((void **)&h->h_chain_err, 64, hipHostMallocMapped));
-    *h->h_chain_err = 0;
     CREATE_CHK(hipEventCreate(&h->ev0));
     CREATE_CHK(hipEventCreate(&h->ev1));
     Params &P = h->P;
@@ -306,11 +307,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     const size_t state_bytes = N * P.RW * 4 + N * SEQ_STRIDE_WORDS * 4;
     CREATE_CHK(hipMalloc(&h->d_state, state_bytes));
     CREATE_CHK(hipMemsetAsync(h->d_state, 0, state_bytes, h->stream));
-    {
-        void *dp = nullptr;
-        CREATE_CHK(hipHostGetDevicePointer(&dp, h->h_chain_err, 0));
-        P.chain_err = (uint32_t *)dp;
-    }
+    // (P.chain_err is set by the first cz_set_overlap(h, 1), together with the second stream)
     CREATE_CHK(hipMalloc(&h->d_stat_u, N * SU_WORDS * 4));
     CREATE_CHK(hipMalloc(&h->d_stat_f, N * SF_WORDS * 8));
     CREATE_CHK(hipMemsetAsync(h->d_stat_u, 0, N * SU_WORDS * 4, h->stream));
@@ -855,6 +852,26 @@ extern "C" int cz_set_overlap(cz_handle h, int32_t enabled) {
         if (!owner.compare_exchange_strong(none, h)) {
             fail(h, "cz_set_overlap: another handle of device %d already overlaps its runs (one per device and process)", h->cfg.device_id);
             return -1;
+        }
+        if (!h->aux_stream) {       // first use: the second stream, the fork event, the pinned word a timed-out hand-off sets
+            void *dp = nullptr;
+            if (hipSetDevice(h->cfg.device_id) != hipSuccess || hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipHostMalloc((void **)&h->h_chain_err, 64, hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer(&dp, h->h_chain_err, 0) != hipSuccess) {
+                owner.store(nullptr);
+                fail(h, "cz_set_overlap: could not create the second stream");
+                return -1;
+            }
+            *h->h_chain_err = 0;
+#ifdef CZ_PROFILE
+            owner.store(nullptr);
+            fail(h, "cz_set_overlap: not available in the diagnostic build");
+            return -1;
+#else
+            h->P.chain_err = (uint32_t *)dp;
+#endif
+            h->tables_version++;
         }
         h->chain_enabled = true;
     } else if (!enabled && was) {

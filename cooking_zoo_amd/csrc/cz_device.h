@@ -75,11 +75,16 @@ struct Params {
     int32_t wt;                    // 1: observation stores are write-through (sc1); chosen per launch by the host
     int32_t walk_touches;          // 1 if carrying an object across cells can change a recipe mark (see cz_load_recipes)
     int32_t wide;                  // 1: wide recipe tables (up to 16 nodes per graph, marks in record words 1 and 7)
-    unsigned long long *stamps;    // diagnostic build only: [N][8] s_memtime stamps (nullptr in the shipped library)
-    uint32_t *chain_err;           // pinned host word: a chained launch whose hand-off never came sets it (cz_sync fails on it)
-    int32_t stop;                  // diagnostic build only: phase index after which the kernel returns (CZ_STOP), else -1
+    int32_t stop;                  // ablation build only: phase index after which the kernel returns (CZ_STOP), else -1
+    // (the argument block is 56 + 264 bytes = five 64-byte lines exactly; one more field costs every launch a sixth)
+#ifdef CZ_PROFILE
+    unsigned long long *stamps;    // diagnostic build only: [N][8] s_memtime stamps (that build does not overlap launches)
+#else
+    uint32_t *chain_err;           // pinned host word: an overlapped launch whose hand-off never came sets it (cz_sync fails on it)
+#endif
     uint32_t seq;                  // per-env hand-off of overlapped launches (SEQ_*); travels as a leading scalar argument
 };
+static_assert(sizeof(Params) == 264, "argument block: see the note above");
 // Overlapped ("chained") launches: consecutive step kernels of a run go to two streams alternately, so a kernel may start
 // while its predecessor still runs; what orders them is a sequence word per env (64 B apart, right behind the records):
 // a wave waits until its env's word equals the launch's number, steps, and publishes number + 1.  The launch boundary

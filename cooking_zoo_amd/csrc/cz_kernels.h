@@ -27,7 +27,7 @@ namespace cz {
 // optimiser cannot see through -- otherwise every one of them is fetched at kernel entry and held in SGPRs for the whole
 // kernel (~30 SGPRs: spills in the non-fused kernel, ~90 spilled SGPRs in the fused one).
 typedef const __attribute__((address_space(4))) Params *KParams;
-struct StepArgsMirror { uint32_t *a; const int32_t *b; const double *c; int32_t i[8]; Params p; };   // k_step's argument list
+struct StepArgsMirror { uint32_t *a; const int32_t *b; const double *c; int32_t i[8]; Params p; };   // (k_step: 7 ints + padding)   // k_step's argument list
 __device__ __forceinline__ KParams late_params(unsigned offset) {
     const __attribute__((address_space(4))) char *k =
         (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -497,12 +497,13 @@ __host__ __device__ inline Early early_of(const Params &P) {
     return Early{P.state, P.actions, P.lut, P.N, P.RW, P.W, P.H, P.D, P.dyn0_off, P.dyn1_off, P.seq};
 }
 
-// CHAIN = true: the one-step kernel of an overlapped run (SEQ_* in cz_device.h) -- its own instantiation, so that the
-// ordinary kernel's prologue stays free of branches (a branch in front of the loads costs 0.8 us per launch there)
-template <int OPL, int CPL, int NA, int SCHEME, bool FUSED, bool CHAIN = false>
-__global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
-                                                          int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
-                                                          int32_t e_dyn1, uint32_t e_seq, const Params P0) {
+// CHAIN = true: the one-step kernel of an overlapped run (SEQ_* in cz_device.h) -- its own kernel (k_step_chain below),
+// so that the ordinary kernel keeps its argument list and a prologue free of branches (a branch in front of the loads
+// costs 0.8 us per launch there)
+template <int OPL, int CPL, int NA, int SCHEME, bool FUSED, bool CHAIN>
+__device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
+                                            int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
+                                            int32_t e_dyn1, uint32_t e_seq, const Params &P0) {
     Params P = P0;
     P.state = e_state; P.actions = e_actions; P.lut = e_lut; P.N = e_N; P.RW = e_RW; P.W = e_W; P.H = e_H; P.D = e_D;
     P.dyn0_off = e_dyn0; P.dyn1_off = e_dyn1;
@@ -538,7 +539,11 @@ __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_st
             if ((++polls & 255u) == 0u) {                   // ~every 50 us: somebody else gave up, or two seconds have passed
                 const uint64_t now = wall_clock64();        // 100 MHz
                 if (t_begin == 0) t_begin = now;
+#ifdef CZ_PROFILE
+                uint32_t *const errw = nullptr;
+#else
                 uint32_t *const errw = CZ_LATE_STEP()->chain_err;
+#endif
                 if (rfl(ldg_dev<uint32_t>(errw, 0)) != 0u || now - t_begin > 200000000ull) {
                     if (lane == 0) __hip_atomic_store(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     abandoned = true;
@@ -650,6 +655,20 @@ __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_st
     CZ_STAMP(7);
 }
 
+template <int OPL, int CPL, int NA, int SCHEME, bool FUSED>
+__global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
+                                                          int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
+                                                          int32_t e_dyn1, const Params P0) {
+    step_kernel<OPL, CPL, NA, SCHEME, FUSED, false>(e_state, e_actions, e_lut, e_N, e_RW, e_W, e_H, e_D, e_dyn0, e_dyn1, 0u, P0);
+}
+// (one more leading scalar: the launch's sequence word; it fills the padding in front of P0, whose offset stays the same)
+template <int OPL, int CPL, int NA, int SCHEME>
+__global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step_chain(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
+                                                                int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
+                                                                int32_t e_dyn1, uint32_t e_seq, const Params P0) {
+    step_kernel<OPL, CPL, NA, SCHEME, false, true>(e_state, e_actions, e_lut, e_N, e_RW, e_W, e_H, e_D, e_dyn0, e_dyn1, e_seq, P0);
+}
+
 // reset(): cooking_env.py:178-210 for envs [env_begin, env_begin + count)
 template <int OPL, int CPL, int NA>
 __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin, const int32_t *__restrict__ layout_ids,
@@ -714,8 +733,8 @@ struct Inst {
         constexpr int EPW = envs_per_wg<CPL>();
         int per_cu = 0;
         hipError_t e;
-        if (P.scheme == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step<OPL, CPL, NA, 3, false, true>, 64 * EPW, 0);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step<OPL, CPL, NA, 1, false, true>, 64 * EPW, 0);
+        if (P.scheme == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step_chain<OPL, CPL, NA, 3>, 64 * EPW, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step_chain<OPL, CPL, NA, 1>, 64 * EPW, 0);
         *envs = (int64_t)per_cu * num_cus * EPW;
         return e;
     }
@@ -732,11 +751,13 @@ struct Inst {
         constexpr int EPW = envs_per_wg<CPL>();
         const dim3 grid((unsigned)((P.N + EPW - 1) / EPW)), block(64 * EPW);
         const Early E = early_of(P);
-#define CZ_LAUNCH_STEP(S, F, ...) \
-    hipLaunchKernelGGL((k_step<OPL, CPL, NA, S, F, ##__VA_ARGS__>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, E.seq, P)
+#define CZ_LAUNCH_STEP(S, F) \
+    hipLaunchKernelGGL((k_step<OPL, CPL, NA, S, F>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, P)
+#define CZ_LAUNCH_CHAIN(S) \
+    hipLaunchKernelGGL((k_step_chain<OPL, CPL, NA, S>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, E.seq, P)
         if (P.actions && (P.seq & SEQ_PUBLISH)) {
-            if (P.scheme == 3) CZ_LAUNCH_STEP(3, false, true);
-            else CZ_LAUNCH_STEP(1, false, true);
+            if (P.scheme == 3) CZ_LAUNCH_CHAIN(3);
+            else CZ_LAUNCH_CHAIN(1);
         } else if (P.actions) {
             if (P.scheme == 3) CZ_LAUNCH_STEP(3, false);
             else CZ_LAUNCH_STEP(1, false);
@@ -745,6 +766,7 @@ struct Inst {
             else CZ_LAUNCH_STEP(1, true);
         }
 #undef CZ_LAUNCH_STEP
+#undef CZ_LAUNCH_CHAIN
         return hipGetLastError();
     }
     static hipError_t step(const Params &P, hipStream_t st) {
