@@ -374,6 +374,8 @@ def worker(args):
                                             ("; the launches OVERLAP pairwise (two streams alternately, per-env sequence words), so "
                                              "this is the launch-to-launch interval: a per-kernel trace shows each kernel resident for "
                                              "about twice as long, two at a time" if overlapped else "")),
+                         "traffic_from": "rocprofv3 --pmc passes of the boundary-ordered kernel (profiles/r02/traffic.json): a counter pass "
+                                         "runs one kernel at a time, which overlapped launches do not survive",
                          "kernel_us_boundary_ordered": kernel_us[1],
                          "frac_boundary_ordered": b_alg * N / (kernel_us[1] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "alg_bytes_per_env_step": b_alg, "units_per_launch": N,
