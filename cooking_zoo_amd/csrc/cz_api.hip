@@ -711,6 +711,8 @@ extern "C" int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_acti
     if (set_device(h)) return 1;
     Params P = h->P;
     P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
+    P.actions = d_actions;
+    if (K >= 2 && chainable(h, P)) return launch_chain(h, P, K, d_actions, action_stride, action_period, 0);   // cz_set_overlap
     for (int32_t k = 0; k < K; ++k) {
         P.actions = d_actions + (int64_t)(k % action_period) * action_stride;
         if (launch_step(h, P)) return 1;

@@ -152,7 +152,7 @@ int cz_ring_prepare(cz_handle h, int32_t K, const int32_t *d_ring, int64_t actio
  * (reset != 0: zero both after reading).  bench.py describes its run from these numbers. */
 int cz_launch_counts(cz_handle h, int64_t *graph_kernels, int64_t *direct_kernels, int32_t reset);
 
-/* OVERLAPPED LAUNCHES (opt-in).  With cz_set_overlap(h, 1), runs of two or more steps of cz_step_device_ring go out with
+/* OVERLAPPED LAUNCHES (opt-in).  With cz_set_overlap(h, 1), runs of two or more steps of cz_step_device_ring / _many go out with
  * consecutive step kernels alternating between the handle's stream and an internal one; every env's step waits for that
  * env's previous step (a sequence word per env, device-scope loads and write-through stores) instead of for the whole
  * previous kernel, so the launch boundary hides behind the neighbouring kernel's work (5.2 instead of 6.2 us per step at

@@ -178,6 +178,19 @@ def test_overlap_is_opt_in_and_one_handle_per_device():
     _ring_run_vs_oracle(a, orc, 10, 4, np.random.default_rng(2))
     L.cz_chain_counts(a._h, C.byref(c), 1)
     assert c.value == 10
+    # cz_step_device_many overlaps the same way
+    rng = np.random.default_rng(3)
+    acts = rng.integers(0, a.n_actions, size=(6, 64, 2), dtype=np.int32)
+    d_acts, d_obs = a.alloc(acts.shape, np.int32), a.alloc((64, 2, a.F), np.float64)
+    d_rew, d_t, d_u = a.alloc((64, 2), np.float64), a.alloc((64, 2), np.uint8), a.alloc((64, 2), np.uint8)
+    d_acts.from_host(acts)
+    _native.check(a._h, L.cz_step_device_many(a._h, 6, d_acts.ptr, 64 * 2, 6, d_obs.ptr, d_rew.ptr, d_t.ptr, d_u.ptr))
+    a.sync()
+    for k in range(6):
+        oo, ro, to, uo = orc.step(acts[k])
+    assert np.array_equal(bits(d_obs.to_host()), bits(oo)) and np.array_equal(strip(a.get_state()), orc.records)
+    L.cz_chain_counts(a._h, C.byref(c), 1)
+    assert c.value == 6
     a.close()                                                                 # releases the right
     assert b.set_overlap(True) is False
     b.close()
