@@ -11,6 +11,7 @@
 //   P1  one stream, ordinary launches (the kernel boundary orders the steps)                  -- what the product does
 //   P2  two streams used alternately, every wave spins on seq[env] == k before it works
 //   P3  one stream, hipExtAnyOrderLaunch, same spin
+//   P4  as P2, but the state words are read by the poll itself (they share the sequence word's 64-byte line)
 // Every spin has a wall-clock deadline.  build: hipcc --offload-arch=gfx950 -O2 -o /tmp/handoff_probe tools/handoff_probe.hip
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
@@ -38,7 +39,19 @@ __global__ __launch_bounds__(WG_THREADS) void k_work(uint32_t *seq, uint32_t exp
     const int lane = (int)(threadIdx.x & 63u);
     const int env = (int)blockIdx.x * 8 + (int)(threadIdx.x >> 6);
     uint32_t *my = seq + (size_t)env * 16;
-    if (spin) {
+    uint32_t merged = 0;
+    if (spin == 2) {
+        // mailbox style: the state words share the sequence word's 64-byte line and come back with the poll itself (one
+        // load per lane covers the line; a line read that shows the new number was served after the data had landed)
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        const uint64_t t0 = wall_clock64();
+        for (;;) {
+            merged = __hip_atomic_load(my + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_readfirstlane(merged) == expect) break;
+            if (wall_clock64() - t0 > DEADLINE_TICKS) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    } else if (spin) {
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;      // somebody gave up: drain quickly
         const uint64_t t0 = wall_clock64();
         while (__hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != expect) {
@@ -50,7 +63,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_work(uint32_t *seq, uint32_t exp
         asm volatile("" ::: "memory");
     }
     // the "state" of the env: read what the previous step left, work on it, write it back (write-through when overlapping)
-    uint32_t x = __hip_atomic_load(my + 1 + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (uint32_t)lane;
+    uint32_t x = spin == 2 ? (uint32_t)__builtin_amdgcn_ds_bpermute((1 + (lane & 7)) << 2, (int)merged) + (uint32_t)lane
+                           : __hip_atomic_load(my + 1 + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (uint32_t)lane;
     for (int i = 0; i < iters; ++i) x = x * 1664525u + 1013904223u + (x >> 7);
     uint4_t v = {x, x ^ 1u, x ^ 2u, x ^ 3u};
     uint4_t *o = out + (size_t)env * 256 + lane;               // 4 KB per env
@@ -86,6 +100,10 @@ int main(int argc, char **argv) {
         for (int k = 0; k < K; ++k) hipLaunchKernelGGL(k_work, dim3(NWG), dim3(WG_THREADS), 0, s[k & 1], seq, (uint32_t)k, 1, it, out, err);
         CHK(hipStreamSynchronize(s[0])); CHK(hipStreamSynchronize(s[1]));
     };
+    auto p4 = [&](int it) {
+        for (int k = 0; k < K; ++k) hipLaunchKernelGGL(k_work, dim3(NWG), dim3(WG_THREADS), 0, s[k & 1], seq, (uint32_t)k, k == 0 ? 1 : 2, it, out, err);
+        CHK(hipStreamSynchronize(s[0])); CHK(hipStreamSynchronize(s[1]));
+    };
     auto p3 = [&](int it) {
         for (int k = 0; k < K; ++k)
             hipExtLaunchKernelGGL(k_work, dim3(NWG), dim3(WG_THREADS), 0, s[0], nullptr, nullptr, k == 0 ? 0 : hipExtAnyOrderLaunch, seq, (uint32_t)k, 1, it, out, err);
@@ -101,14 +119,15 @@ int main(int argc, char **argv) {
         if (iters == 0) iters = 1200;
         printf("using iters = %d\n", iters);
     }
-    const char *names[3] = {"P1 one stream, kernel boundaries", "P2 two streams alternately + per-env spin", "P3 one stream, any-order launches + per-env spin"};
+    const char *names[4] = {"P1 one stream, kernel boundaries", "P2 two streams alternately + per-env spin", "P3 one stream, any-order launches + per-env spin",
+                            "P4 as P2, state in the sequence word's line (one round trip less)"};
     for (int rep = 0; rep < 2; ++rep)
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < 4; ++p) {
             reset();
-            if (p == 0) p1(iters); else if (p == 1) p2(iters); else p3(iters);
+            if (p == 0) p1(iters); else if (p == 1) p2(iters); else if (p == 2) p3(iters); else p4(iters);
             reset();
             double t0 = now();
-            if (p == 0) p1(iters); else if (p == 1) p2(iters); else p3(iters);
+            if (p == 0) p1(iters); else if (p == 1) p2(iters); else if (p == 2) p3(iters); else p4(iters);
             double t1 = now();
             uint32_t herr = 0, last = 0;
             CHK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));

@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""GPU box: the largest batch whose runs may go out as overlapped launches (cz_overlap_limit), per kernel instance."""
 import sys; sys.path.insert(0,'/root/repo')
 from cooking_zoo_amd.vec_env import CookingVecEnv
 from cooking_zoo_amd import _native
