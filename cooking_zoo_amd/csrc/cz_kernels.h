@@ -530,12 +530,25 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     static_assert(!(FUSED && CHAIN), "overlapped launches are one-step launches");
     constexpr bool chained = CHAIN;
     bool abandoned = false;
+    int av = 0;
+    if (CHAIN) {
+        // What does not depend on the predecessor happens before the wait: the actions, the constant part of the LDS image
+        // and the workgroup's table with its barrier.  With the barrier in front of the wait the eight envs of a workgroup
+        // stay independent - behind it, every one of them would start only when the slowest of the eight predecessors is done.
+        av = ldg<int>(P.actions + (size_t)env * NA, (uint32_t)min(lane, NA - 1) * 4u);
+        init_lds<CPL>(P, cx, lds);
+        if (threadIdx.x < (unsigned)LUT_SIZE) lut[threadIdx.x] = lutv;
+        __syncthreads();
+    }
     if (CHAIN && (e_seq & SEQ_WAIT) && env_raw < P.N) {
         const uint32_t want = e_seq & SEQ_MASK;
         uint32_t polls = 0;
         uint64_t t_begin = 0;
+#ifndef CZ_POLL_SLEEP
+#define CZ_POLL_SLEEP 1
+#endif
         while (rfl(ldg_dev<uint32_t>(seqw, 0)) != want) {
-            __builtin_amdgcn_s_sleep(1);
+            if (CZ_POLL_SLEEP > 0) __builtin_amdgcn_s_sleep(CZ_POLL_SLEEP);
             if ((++polls & 255u) == 0u) {                   // ~every 50 us: somebody else gave up, or two seconds have passed
                 const uint64_t now = wall_clock64();        // 100 MHz
                 if (t_begin == 0) t_begin = now;
@@ -553,20 +566,21 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         }
     }
     // ---- every load of the step is issued here, before anything waits
-    int av = 0;
-    if (!FUSED) av = ldg<int>(P.actions + (size_t)env * NA, (uint32_t)min(lane, NA - 1) * 4u);
+    if (!FUSED && !CHAIN) av = ldg<int>(P.actions + (size_t)env * NA, (uint32_t)min(lane, NA - 1) * 4u);
     double ret = ldrec<double>(chained, retp, ((uint32_t)lane & 3u) * 8u);                                       // running episode return, lane a = agent a
     Env<OPL, CPL, NA> e;
     load_env(P, e, cx, rec, chained);
-    init_lds<CPL>(P, cx, lds);
+    if (!CHAIN) init_lds<CPL>(P, cx, lds);
     uint32_t rowv = load_recipe_rows(P, e.recipes, lane);
     uint32_t dsc[OBS_CHUNK];
     if (P.obs) load_desc(P, e.layout, 0, lane, dsc);
     const int64_t env_global = P.env_id_base + env;
     bool cells_dirty = false, objs_dirty = false, header_dirty = FUSED;
     bool img_objs = true, img_cells = true;                 // which parts of the LDS image the next encode must rebuild
-    if (threadIdx.x < (unsigned)LUT_SIZE) lut[threadIdx.x] = lutv;
-    __syncthreads();
+    if (!CHAIN) {
+        if (threadIdx.x < (unsigned)LUT_SIZE) lut[threadIdx.x] = lutv;
+        __syncthreads();
+    }
     if (env_raw >= P.N || (CHAIN && abandoned)) return;
     CZ_STAMP(1);
 
