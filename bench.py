@@ -166,7 +166,22 @@ def aggregate(per_rank, K):
             "ms_per_step_max": ms[-1], "env_steps_per_region": steps[order[R // 2]], "repeats": R}
 
 
+def emit(line):
+    """the one JSON line, on the process's real stdout (see worker)"""
+    os.write(_REAL_STDOUT, (json.dumps(line) + "\n").encode())
+
+
+_REAL_STDOUT = 1
+
+
 def worker(args):
+    # Native libraries print to stdout through C stdio (RCCL's version banner, for one), and whether that reaches fd 1
+    # before or after this script's own line depends on who flushes when.  So fd 1 is handed to stderr for the whole
+    # run, and the JSON line goes to a private duplicate of the real stdout: nothing else can appear there.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     from cooking_zoo_amd import distributed as czd
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -189,7 +204,7 @@ def worker(args):
                     "shards": [czd.shard_range(N * world, world, r) for r in range(world)],
                     "stats_total_env_steps": sum(e["stats"]["env_steps"] for e in every)}
             line.update(aggregate(every, K))
-            print(json.dumps(line), flush=True)
+            emit(line)
         rdzv.close()
         return 0
 
@@ -204,6 +219,8 @@ def worker(args):
     # CZ_CHAIN=0 keeps the launch-boundary ordering with graph replay)
     if os.environ.get("CZ_CHAIN", "1") != "0":
         env.set_overlap(True)
+        if os.environ.get("CZ_BENCH_SIMULATE_HANDOFF_TIMEOUT"):          # (test hook for the fallback in single_gpu_with_fallback)
+            raise RuntimeError("simulated: an overlapped launch gave up waiting for its predecessor")
 
     # inputs resident in HBM: a ring of int32 [N, A] action tensors, one slot per step (uniform over the 5 scheme3
     # actions); outputs: obs f64 [N, A, F], rewards f64, terminations / truncations u8.  The ring holds a whole number of
@@ -391,20 +408,38 @@ def worker(args):
             line["fused_rollout"] = fused
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(env)
-        print(json.dumps(line), flush=True)
+        emit(line)
     try:
         rdzv.close()
     except Exception:
         pass
-    # RCCL prints a version banner through C stdio, which reaches fd 1 when the process exits: after the JSON line nothing
-    # else may appear on stdout, so fd 1 is pointed at /dev/null for whatever the libraries still hold in their buffers
     sys.stdout.flush()
-    os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if rc != 0:
         sys.stdout.flush()
         os._exit(rc)                             # a communicator stuck in bring-up cannot be torn down: leave, visibly failed
     env.close()
     return 0
+
+
+def single_gpu_with_fallback(args):
+    """One rank: run the worker; if an overlapped launch ever gives up on its hand-off (the library then refuses to go on,
+    the env states are void), measure again in a fresh child process with launch-boundary ordering (CZ_CHAIN=0) and say so
+    in the line, rather than leaving the caller without a result."""
+    try:
+        return worker(args)
+    except Exception as exc:                                     # noqa: BLE001  (NativeError lives in a module imported later)
+        if "gave up waiting" not in str(exc) or os.environ.get("CZ_CHAIN", "1") == "0":
+            raise
+        print(f"bench.py: {exc}\nbench.py: measuring again with CZ_CHAIN=0", file=sys.stderr)
+        import subprocess
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=dict(os.environ, CZ_CHAIN="0"),
+                             stdout=subprocess.PIPE, text=True)
+        for ln in out.stdout.splitlines():
+            if ln.startswith("{"):
+                line = json.loads(ln)
+                line["overlap_fallback"] = f"overlapped launches were abandoned in this run ({exc}); measured with CZ_CHAIN=0"
+                emit(line)
+        return out.returncode
 
 
 def main():
@@ -414,7 +449,7 @@ def main():
         # library); every rank is a fresh interpreter that pins its own device.
         from cooking_zoo_amd.distributed import launch_local
         sys.exit(launch_local(args.gpus, [os.path.abspath(__file__), *sys.argv[1:]], timeout=3600.0))
-    sys.exit(worker(args))
+    sys.exit(single_gpu_with_fallback(args) if int(os.environ.get("WORLD_SIZE", "1")) == 1 else worker(args))
 
 
 if __name__ == "__main__":

@@ -130,7 +130,7 @@ struct cz_handle_s {
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr;
     bool chain_enabled = false;        // cz_set_overlap / CZ_CHAIN=1; off: runs are ordered by launch boundaries only (graph replay)
-    int64_t chain_max_envs = 0;        // largest batch that may overlap (2/3 of the waves the device holds, see cz_create)
+    int64_t chain_max_envs = 0;        // largest batch that may overlap (half of the envs the device holds at once, see cz_create)
     uint32_t seq_counter = 0;          // number of the next chained launch (mod 2^30)
     uint32_t *h_chain_err = nullptr;   // pinned, device-mapped: set by a wave whose hand-off never came
     int64_t n_chained_kernels = 0;
@@ -284,15 +284,15 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     h->kl = (P.D <= 64 && C <= 64) ? launchers_small() : (P.D <= 128 && C <= 256) ? launchers_large() : launchers_huge();
     h->huge = P.D > 128 || C > 256;
     {   // Overlapped launches: a kernel's waves spin until their predecessors, waves of the previous kernel, have run.  A
-        // wave that waits for a workgroup which cannot be dispatched because the waiting waves hold every slot would wait
-        // forever; so the waiting kernel (N waves at most) must never be able to fill the device: N <= 2/3 of the waves the
-        // device holds of this kernel leaves the predecessor a third of the slots at the very least (its workgroups were
-        // queued first, and at most two of these kernels are in flight: the third waits for the first on its stream).
+        // wave that waits for a workgroup which cannot be dispatched because waiting waves hold the slots it needs would
+        // wait forever, so two of these kernels must fit the device IN FULL, together: N <= half of the envs the device
+        // holds of this kernel (at most two are ever in flight: the third waits for the first on its stream).  A weaker
+        // rule - the waiting kernel alone must not fill the device, 2/3 - timed out at the start of runs on some boxes.
         hipDeviceProp_t prop;
         CREATE_CHK(hipGetDeviceProperties(&prop, cfg->device_id));
         int64_t resident = 0;
         CREATE_CHK(h->kl.resident_envs(P, prop.multiProcessorCount, &resident));
-        h->chain_max_envs = resident * 2 / 3;
+        h->chain_max_envs = resident / 2;
     }
     {   // the reward of a step on which no recipe node changed: cooking_env.py:304-307 with zero deltas, same op order
         double x = 0.0;
@@ -386,8 +386,27 @@ extern "C" int32_t cz_record_words(cz_handle h) { return h ? h->P.RW : 0; }
 extern "C" int cz_sync(cz_handle h) {
     if (!h) return fail(nullptr, "null handle");
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->h_chain_err && *(volatile uint32_t *)h->h_chain_err)
-        return fail(h, "cz_sync: an overlapped launch gave up waiting for its predecessor (the envs' states are no longer trustworthy)");
+    if (h->h_chain_err && *(volatile uint32_t *)h->h_chain_err) {
+        const uint32_t w = *(volatile uint32_t *)h->h_chain_err;
+        if (getenv("CZ_CHAIN_DEBUG")) {          // histogram of the sequence words at the time of the report
+            (void)hipDeviceSynchronize();
+            std::vector<uint32_t> sq((size_t)h->P.N * SEQ_STRIDE_WORDS);
+            (void)hipMemcpy(sq.data(), h->d_state + (size_t)h->P.N * h->P.RW, sq.size() * 4, hipMemcpyDeviceToHost);
+            uint32_t lo = ~0u, hi = 0;
+            for (int e = 0; e < h->P.N; ++e) { lo = sq[(size_t)e * SEQ_STRIDE_WORDS] < lo ? sq[(size_t)e * SEQ_STRIDE_WORDS] : lo; hi = sq[(size_t)e * SEQ_STRIDE_WORDS] > hi ? sq[(size_t)e * SEQ_STRIDE_WORDS] : hi; }
+            fprintf(stderr, "[cz] sequence words: min %u max %u;", lo, hi);
+            for (uint32_t v = lo; v <= hi && v < lo + 8; ++v) {
+                int cnt = 0, first = -1, last = -1;
+                for (int e = 0; e < h->P.N; ++e)
+                    if (sq[(size_t)e * SEQ_STRIDE_WORDS] == v) { ++cnt; if (first < 0) first = e; last = e; }
+                fprintf(stderr, " value %u: %d envs (first %d, last %d);", v, cnt, first, last);
+            }
+            fprintf(stderr, "\n");
+        }
+        return fail(h, "cz_sync: an overlapped launch gave up waiting for its predecessor (the envs' states are no longer trustworthy): "
+                       "waited for number %u, last saw ...%u (mod 64), the handle's next number is %u",
+                    w & 0xFFFFFFu, (w >> 24) & 63u, h->seq_counter);
+    }
     return 0;
 }
 

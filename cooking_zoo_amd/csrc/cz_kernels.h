@@ -557,8 +557,12 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
 #else
                 uint32_t *const errw = CZ_LATE_STEP()->chain_err;
 #endif
-                if (rfl(ldg_dev<uint32_t>(errw, 0)) != 0u || now - t_begin > 200000000ull) {
-                    if (lane == 0) __hip_atomic_store(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const uint32_t seen = rfl(ldg_dev<uint32_t>(errw, 0));
+                if (seen != 0u || now - t_begin > 200000000ull) {
+                    // first reporter: what it waited for (low 24 bits), what it last saw there (next 6), bit 31
+                    if (lane == 0 && seen == 0u)
+                        __hip_atomic_store(errw, 0x80000000u | ((rfl(ldg_dev<uint32_t>(seqw, 0)) & 63u) << 24) | (want & 0xFFFFFFu), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
                     abandoned = true;
                     break;
                 }
@@ -676,8 +680,21 @@ __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_st
     step_kernel<OPL, CPL, NA, SCHEME, FUSED, false>(e_state, e_actions, e_lut, e_N, e_RW, e_W, e_H, e_D, e_dyn0, e_dyn1, 0u, P0);
 }
 // (one more leading scalar: the launch's sequence word; it fills the padding in front of P0, whose offset stays the same)
+// Eight waves per SIMD (<= 96 SGPRs, at the price of ~45 spilled ones): four workgroups per CU, so that two of these
+// kernels are resident IN FULL at the batch sizes that may overlap.  With the 106 SGPRs the compiler takes by itself only
+// three workgroups fit a CU, a waiting kernel (512 workgroups at 4096 envs) then leaves its predecessor a third of the
+// device, and on some boxes the predecessor's queued workgroups did not get in for seconds (hand-off timeouts at the start
+// of a run, where the first kernel of the second stream can be resident before its predecessor is).
+#ifndef CZ_CHAIN_WPE
+#define CZ_CHAIN_WPE 8
+#endif
+#if CZ_CHAIN_WPE > 0
+#define CZ_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(CZ_CHAIN_WPE, CZ_CHAIN_WPE)))
+#else
+#define CZ_CHAIN_ATTR
+#endif
 template <int OPL, int CPL, int NA, int SCHEME>
-__global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step_chain(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
+__global__ __launch_bounds__(64 * envs_per_wg<CPL>()) CZ_CHAIN_ATTR void k_step_chain(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
                                                                 int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
                                                                 int32_t e_dyn1, uint32_t e_seq, const Params P0) {
     step_kernel<OPL, CPL, NA, SCHEME, false, true>(e_state, e_actions, e_lut, e_N, e_RW, e_W, e_H, e_D, e_dyn0, e_dyn1, e_seq, P0);

@@ -140,9 +140,9 @@ def test_overlapped_runs_match_oracle(level, meta, agents, recipes, scheme):
 
 @pytest.mark.parametrize("n,overlaps", [(4096, True), (16384, False)])
 def test_long_ring_runs_at_and_above_the_overlap_limit(n, overlaps):
-    """300-step runs of the config-2 workload.  4096 envs: a kernel's waiting waves leave at least a third of the device
-    to its predecessor, so the run goes out as overlapped launches.  16 384 envs: the waiting waves could hold every slot
-    their predecessors still need, so the library must not overlap (it replays graphs) - and says so."""
+    """300-step runs of the config-2 workload.  4096 envs: two step kernels are resident in full at the same time, so the
+    run goes out as overlapped launches.  16 384 envs: waiting waves could hold the slots their predecessors still need,
+    so the library must not overlap (it replays graphs) - and says so."""
     import ctypes as C
     from cooking_zoo_amd import _native
     from oracle_binding import ShardedOracle

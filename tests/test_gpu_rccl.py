@@ -64,3 +64,7 @@ def test_bench_single_gpu_goes_through_the_multi_rank_code():
     assert d["runtime"]["torch_imported"] is False and "/opt/rocm" in d["runtime"]["hip"]
     assert d["value"] > 1e6 and d["value_min"] <= d["value"] <= d["value_max"]
     assert 0 < d["roofline"]["frac"] < 1
+    # a hand-off that times out must not leave the caller without a line: measured again with launch-boundary ordering
+    d = run(CZ_BENCH_SIMULATE_HANDOFF_TIMEOUT="1")
+    assert "gave up waiting" in d["overlap_fallback"] and "timed launches 0 went out as overlapped launches" in d["config"]["api"]
+    assert d["value"] > 1e6
