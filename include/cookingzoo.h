@@ -160,8 +160,9 @@ int cz_launch_counts(cz_handle h, int64_t *graph_kernels, int64_t *direct_kernel
  * later work on it (or cz_sync) sees the whole run.
  *   - Only batches of at most cz_overlap_limit(h) envs overlap (two of these kernels must be resident in full at the
  *     same time, or waiting waves could hold the slots their predecessors need: half of the envs the device holds of
- *     this kernel; 4096 envs for the 7x7 levels on an MI355X), only while the observation stores are write-through (up to 128 MiB of observations per step), and
- *     never inside a stream capture of the caller.  Everything else is replayed from graphs as before.
+ *     this kernel, counted for an otherwise idle device - kernels of the caller that hold compute units for long while a
+ *     run is in flight take that room away; 4096 envs for the 7x7 levels on an MI355X), only while the observation
+ *     stores are write-through (up to 128 MiB of observations per step), and never inside a stream capture of the caller.  Everything else is replayed from graphs as before.
  *   - One handle per device and process may have it switched on (cz_set_overlap returns -1 for a second one): the
  *     waiting kernels of two handles together could fill the device.  CZ_CHAIN=1 switches it on at cz_create.
  *   - A hand-off that does not arrive within two seconds marks the handle (cz_sync then fails) instead of hanging.
