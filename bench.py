@@ -174,7 +174,47 @@ def emit(line):
 _REAL_STDOUT = 1
 
 
+_LAST_ENV = None
+
+
 def worker(args):
+    """Measures with overlapped launches first (unless CZ_CHAIN=0).  If any rank's library ever abandons a hand-off (it then
+    refuses to go on: the env states are void), that rank declares the attempt's rendezvous void, every rank drops its env
+    and communicator, and all of them measure again with launch-boundary ordering - the line then says so."""
+    global _LAST_ENV
+    _redirect_stdout()
+    from cooking_zoo_amd import distributed as czd
+    base = czd.FileRendezvous.from_env(timeout=600.0)
+    sim = os.environ.get("CZ_BENCH_SIMULATE_HANDOFF_TIMEOUT")            # test hook: "1" = every rank, "10r" = rank r only
+    want = os.environ.get("CZ_CHAIN", "1") != "0" and (not args.dry_run or bool(sim))
+    note, rc = None, 1
+    for attempt, overlap in enumerate([True, False] if want else [False]):
+        rdzv = base.subdir(f"attempt{attempt}")
+        try:
+            rc = worker_body(args, rdzv, overlap, note)
+            break
+        except Exception as exc:                                  # noqa: BLE001
+            abandoned, poisoned = "gave up waiting" in str(exc), isinstance(exc, czd.RendezvousPoisoned)
+            if not overlap or not (abandoned or poisoned):
+                raise
+            if abandoned:
+                rdzv.poison(str(exc))
+            print(f"bench.py rank {rdzv.rank}: {exc}\nbench.py: measuring again with launch-boundary ordering", file=sys.stderr)
+            note = f"overlapped launches were abandoned in the first attempt ({exc}); measured with launch-boundary ordering"
+            if _LAST_ENV is not None:
+                try:
+                    _LAST_ENV.close()
+                except Exception:                                 # noqa: BLE001
+                    pass
+                _LAST_ENV = None
+    try:
+        base.close()
+    except Exception:                                             # noqa: BLE001
+        pass
+    return rc
+
+
+def _redirect_stdout():
     # Native libraries print to stdout through C stdio (RCCL's version banner, for one), and whether that reaches fd 1
     # before or after this script's own line depends on who flushes when.  So fd 1 is handed to stderr for the whole
     # run, and the JSON line goes to a private duplicate of the real stdout: nothing else can appear there.
@@ -182,17 +222,23 @@ def worker(args):
     sys.stdout.flush()
     _REAL_STDOUT = os.dup(1)
     os.dup2(2, 1)
+
+
+def worker_body(args, rdzv, overlap, note):
+    global _LAST_ENV
     from cooking_zoo_amd import distributed as czd
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used", file=sys.stderr)
-    rdzv = czd.FileRendezvous.from_env(timeout=600.0)
     N, K, Wm, R = args.envs, args.steps, args.warmup, max(1, args.repeats)
     begin, count = czd.shard_range(N * world, world, rank)
 
+    sim = os.environ.get("CZ_BENCH_SIMULATE_HANDOFF_TIMEOUT")
     if args.dry_run:
+        if overlap and sim and (sim == "1" or int(sim) == rank + 100):
+            raise RuntimeError("simulated: an overlapped launch gave up waiting for its predecessor")
         mine = {"elapsed_s": [1e-3 * (rank + 1 + 0.01 * r) for r in range(R)], "env_steps": [K * count] * R,
                 "kernel_us": [1.0] * R, "stats": {"env_steps": K * count * R}}
         every = [json.loads(b) for b in rdzv.all_gather(json.dumps(mine).encode())]
@@ -204,6 +250,8 @@ def worker(args):
                     "shards": [czd.shard_range(N * world, world, r) for r in range(world)],
                     "stats_total_env_steps": sum(e["stats"]["env_steps"] for e in every)}
             line.update(aggregate(every, K))
+            if note:
+                line["overlap_fallback"] = note
             emit(line)
         rdzv.close()
         return 0
@@ -213,13 +261,14 @@ def worker(args):
     env = CookingVecEnv(count, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"],
                         action_scheme="scheme3", num_layouts=256, layout_seed=0, auto_reset=True,
                         device_id=local_rank, env_id_base=begin)
+    _LAST_ENV = env
     L, h = _native.lib(), env._h
     env.reset(return_obs=False)
     # this process drives one handle on its GPU: runs of step launches may overlap (cz_set_overlap in include/cookingzoo.h;
     # CZ_CHAIN=0 keeps the launch-boundary ordering with graph replay)
-    if os.environ.get("CZ_CHAIN", "1") != "0":
+    if overlap:
         env.set_overlap(True)
-        if os.environ.get("CZ_BENCH_SIMULATE_HANDOFF_TIMEOUT"):          # (test hook for the fallback in single_gpu_with_fallback)
+        if sim and (sim == "1" or int(sim) == rank + 100):         # test hook for the second attempt
             raise RuntimeError("simulated: an overlapped launch gave up waiting for its predecessor")
 
     # inputs resident in HBM: a ring of int32 [N, A] action tensors, one slot per step (uniform over the 5 scheme3
@@ -404,6 +453,8 @@ def worker(args):
             "runtime": {"hip": hip_path.value.decode(), "rccl": rccl_path.value.decode(), "torch_imported": "torch" in sys.modules},
             "episode_stats_allgather": stats_all,
         }
+        if note:
+            line["overlap_fallback"] = note
         if fused is not None:
             line["fused_rollout"] = fused
         if world == 1 and not args.no_cpu_baseline:
@@ -418,28 +469,8 @@ def worker(args):
         sys.stdout.flush()
         os._exit(rc)                             # a communicator stuck in bring-up cannot be torn down: leave, visibly failed
     env.close()
+    _LAST_ENV = None
     return 0
-
-
-def single_gpu_with_fallback(args):
-    """One rank: run the worker; if an overlapped launch ever gives up on its hand-off (the library then refuses to go on,
-    the env states are void), measure again in a fresh child process with launch-boundary ordering (CZ_CHAIN=0) and say so
-    in the line, rather than leaving the caller without a result."""
-    try:
-        return worker(args)
-    except Exception as exc:                                     # noqa: BLE001  (NativeError lives in a module imported later)
-        if "gave up waiting" not in str(exc) or os.environ.get("CZ_CHAIN", "1") == "0":
-            raise
-        print(f"bench.py: {exc}\nbench.py: measuring again with CZ_CHAIN=0", file=sys.stderr)
-        import subprocess
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=dict(os.environ, CZ_CHAIN="0"),
-                             stdout=subprocess.PIPE, text=True)
-        for ln in out.stdout.splitlines():
-            if ln.startswith("{"):
-                line = json.loads(ln)
-                line["overlap_fallback"] = f"overlapped launches were abandoned in this run ({exc}); measured with CZ_CHAIN=0"
-                emit(line)
-        return out.returncode
 
 
 def main():
@@ -449,7 +480,7 @@ def main():
         # library); every rank is a fresh interpreter that pins its own device.
         from cooking_zoo_amd.distributed import launch_local
         sys.exit(launch_local(args.gpus, [os.path.abspath(__file__), *sys.argv[1:]], timeout=3600.0))
-    sys.exit(single_gpu_with_fallback(args) if int(os.environ.get("WORLD_SIZE", "1")) == 1 else worker(args))
+    sys.exit(worker(args))
 
 
 if __name__ == "__main__":

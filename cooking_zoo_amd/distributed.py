@@ -110,6 +110,10 @@ class RendezvousTimeout(RuntimeError):
     pass
 
 
+class RendezvousPoisoned(RuntimeError):
+    """another rank has declared this rendezvous void (`FileRendezvous.poison`): whoever waits in it, or enters it, stops"""
+
+
 class FileRendezvous:
     """Small-message collectives between the ranks of ONE node through a shared directory (tmpfs).
 
@@ -144,7 +148,27 @@ class FileRendezvous:
     def _file(self, seq: int, rank: int) -> str:
         return os.path.join(self.path, f"{seq}.{rank}")
 
+    def subdir(self, name: str) -> "FileRendezvous":
+        """A fresh rendezvous (call numbers start at 0 again) in a sub-directory, for a phase all ranks (re)start together."""
+        return FileRendezvous(os.path.join(self.path, name), self.rank, self.world, self.timeout)
+
+    def poison(self, reason: str) -> None:
+        """Declare this rendezvous void: every rank that waits in it or enters it from now on raises RendezvousPoisoned
+        (used when one rank has to abandon a phase that the others are still in)."""
+        tmp = os.path.join(self.path, f"poison.tmp.{self.rank}")
+        with open(tmp, "w") as f:
+            f.write(reason)
+        os.rename(tmp, os.path.join(self.path, "poison"))
+
+    def _check_poison(self) -> None:
+        try:
+            with open(os.path.join(self.path, "poison")) as f:
+                raise RendezvousPoisoned(f.read())
+        except FileNotFoundError:
+            pass
+
     def all_gather(self, payload: bytes) -> List[bytes]:
+        self._check_poison()
         seq, self._seq = self._seq, self._seq + 1
         tmp = self._file(seq, self.rank) + ".tmp"
         with open(tmp, "wb") as f:
@@ -163,6 +187,7 @@ class FileRendezvous:
                 except FileNotFoundError:
                     pass
             if missing:
+                self._check_poison()
                 if time.monotonic() > deadline:
                     raise RendezvousTimeout(f"rank {self.rank}: ranks {sorted(missing)} did not reach collective #{seq} "
                                             f"within {self.timeout:.0f} s")
@@ -181,7 +206,7 @@ class FileRendezvous:
         not read from it again (a `bye.<rank>` file written after that rank has left the final barrier)."""
         try:
             self.barrier()
-        except RendezvousTimeout:
+        except (RendezvousTimeout, RendezvousPoisoned):
             pass
         if self.rank != 0:
             try:

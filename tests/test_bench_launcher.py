@@ -102,3 +102,18 @@ def test_file_rendezvous_collectives_and_timeout(tmp_path):
     lonely = FileRendezvous(str(tmp_path / "rv2"), 0, 2, timeout=0.3)
     with pytest.raises(RendezvousTimeout):
         lonely.barrier()
+
+
+@pytest.mark.parametrize("who", ["1", "101", "100"])
+def test_abandoned_hand_off_makes_every_rank_measure_again(who):
+    """One rank (or every rank) hits the 'an overlapped launch gave up waiting' error in the first attempt: it declares
+    the attempt's rendezvous void, the other rank - blocked in that rendezvous - notices, both start over with
+    launch-boundary ordering, and the one line says what happened."""
+    p = _run_bench("--gpus", "2", "--dry-run", "--steps", "20", "--warmup", "5", "--repeats", "3", "--envs", "64",
+                   env={"CZ_BENCH_SIMULATE_HANDOFF_TIMEOUT": who})
+    assert p.returncode == 0, p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "gave up waiting" in d["overlap_fallback"]
+    assert "measuring again with launch-boundary ordering" in p.stderr
