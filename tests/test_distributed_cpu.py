@@ -114,3 +114,40 @@ def test_stats_struct_roundtrip():
     st = dict(env_steps=123456789012, episodes=77, length_sum=3080, truncations=70, terminations=7,
               recipes_completed=[3, 4, 0, 0], return_sum=[-12.5, 19.9875, 0.0, 0.0])
     assert stats_from_bytes(stats_to_bytes(st)) == st
+
+
+def test_rendezvous_poison_wakes_waiting_ranks_and_a_fresh_subdir_starts_over(tmp_path):
+    """FileRendezvous.poison: a rank that waits in a collective (or enters one later) raises RendezvousPoisoned with the
+    reason; `subdir` gives every rank a fresh rendezvous whose call numbers start at 0 again (bench.py's second attempt)."""
+    import threading
+    from cooking_zoo_amd.distributed import FileRendezvous, RendezvousPoisoned
+    base = [FileRendezvous(str(tmp_path / "r"), r, 2, timeout=20.0) for r in range(2)]
+    first = [b.subdir("attempt0") for b in base]
+    got = {}
+    t0 = threading.Thread(target=lambda: got.__setitem__("ag0", first[0].all_gather(b"a")))
+    t0.start()
+
+    def rank0():
+        try:
+            first[0].barrier()                                     # rank 1 never comes: it poisons instead
+        except RendezvousPoisoned as e:
+            got["r0"] = str(e)
+    # complete the all_gather above for rank 1, then let rank 0 wait in a barrier
+    assert first[1].all_gather(b"b") == [b"a", b"b"]
+    t0.join(10)
+    assert got["ag0"] == [b"a", b"b"]
+    t = threading.Thread(target=rank0)
+    t.start()
+    first[1].poison("hand-off abandoned on rank 1")
+    t.join(10)
+    assert got.get("r0") == "hand-off abandoned on rank 1"
+    with pytest.raises(RendezvousPoisoned):
+        first[1].barrier()                                         # entering it later fails as well
+    second = [b.subdir("attempt1") for b in base]
+    out = {}
+    ts = [threading.Thread(target=lambda r=r: out.__setitem__(r, second[r].all_gather(bytes([r])))) for r in range(2)]
+    for x in ts:
+        x.start()
+    for x in ts:
+        x.join(10)
+    assert out[0] == out[1] == [b"\x00", b"\x01"]
