@@ -160,6 +160,38 @@ def test_long_ring_runs_at_and_above_the_overlap_limit(n, overlaps):
     env.close()
 
 
+def test_many_short_overlapped_runs_at_the_limit():
+    """the start of a run is where the first kernel of the second stream can be resident before its predecessor is: 80
+    runs of 2-40 steps at the overlap limit (the two kernels in flight fill the device), mostly without synchronising
+    in between (tools/overlap_stress.py is the long version)"""
+    from cooking_zoo_amd import _native
+    from oracle_binding import ShardedOracle
+    n, A, period = 4096, 2, 32
+    env = make(n, "coop_test", "example", A, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3", max_steps=40, num_layouts=64)
+    env.set_overlap(True)
+    assert n <= env.overlap_limit()
+    orc = ShardedOracle(env)
+    assert np.array_equal(bits(env.reset()), bits(orc.reset()))
+    L = _native.lib()
+    rng = np.random.default_rng(9)
+    ring_host = rng.integers(0, env.n_actions, size=(period, n, A), dtype=np.int32)
+    d_ring = env.alloc((period, n, A), np.int32)
+    d_ring.from_host(ring_host)
+    d_obs, d_rew = env.alloc((n, A, env.F), np.float64), env.alloc((n, A), np.float64)
+    d_t, d_u = env.alloc((n, A), np.uint8), env.alloc((n, A), np.uint8)
+    for r in range(80):
+        K, first = int(rng.integers(2, 41)), int(rng.integers(period))
+        _native.check(env._h, L.cz_step_device_ring(env._h, K, d_ring.ptr, n * A, period, first, d_obs.ptr, d_rew.ptr, d_t.ptr, d_u.ptr))
+        if r % 7 == 0:
+            env.sync()
+        for k in range(K):
+            oo, ro, to, uo = orc.step(ring_host[(first + k) % period], False)
+    env.sync()
+    assert np.array_equal(strip(env.get_state()), orc.records)
+    assert np.array_equal(bits(d_rew.to_host()), bits(ro)) and np.array_equal(d_t.to_host(), to) and np.array_equal(d_u.to_host(), uo)
+    env.close()
+
+
 def test_overlap_is_opt_in_and_one_handle_per_device():
     import ctypes as C
     from cooking_zoo_amd import _native
