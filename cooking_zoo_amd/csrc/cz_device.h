@@ -97,6 +97,9 @@ constexpr int SEQ_STRIDE_WORDS = 16;
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rdl(uint32_t v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// the inverse: a wave-uniform lane mask as a per-lane predicate.  Costs no instruction - the SGPR pair becomes the condition
+// operand of the select that consumes it
+__device__ __forceinline__ bool lanes(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 // v_writelane_b32: clang 22 / ROCm 7.2 has no builtin for it; bind the LLVM intrinsic the way the HIP headers do
 extern "C" __device__ uint32_t __cz_writelane(uint32_t, uint32_t, uint32_t) __asm("llvm.amdgcn.writelane.i32");
 __device__ __forceinline__ uint32_t wrl(uint32_t value, int lane, uint32_t into) { return __cz_writelane(value, (uint32_t)lane, into); }
@@ -223,6 +226,12 @@ struct Ops {
     using OM = Mask<OPL>;
     using CM = Mask<CPL>;
 
+    // Coding rule of this file (it decides the instruction count): a per-lane predicate is either ONE comparison handed to
+    // ballot() - which is then a single v_cmp writing an SGPR pair - or a wave-uniform 64-bit lane mask combined with
+    // scalar and / or / andn2 and handed back to the lanes with lanes(mask), which costs nothing (the mask is the condition
+    // operand of the v_cndmask).  ballot(a && b) on the other hand makes the compiler materialise 0 / 1 in a VGPR and
+    // compare again (two more VALU instructions per use).
+
     // ---- uniform reads / predicated writes of one slot / one cell ---------------------------------------
     static __device__ __forceinline__ uint32_t slot_d0(const E &e, int s) {
         if (OPL == 1) return rdl(e.d0[0], s);
@@ -230,6 +239,14 @@ struct Ops {
 #pragma unroll
         for (int k = 0; k < OPL; ++k)
             if ((s >> 6) == k) v = rdl(e.d0[k], s & 63);
+        return v;
+    }
+    static __device__ __forceinline__ uint32_t slot_d1(const E &e, int s) {
+        if (OPL == 1) return rdl(e.d1[0], s);
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < OPL; ++k)
+            if ((s >> 6) == k) v = rdl(e.d1[k], s & 63);
         return v;
     }
     static __device__ __forceinline__ uint32_t cell_at(const E &e, int c) {
@@ -242,71 +259,84 @@ struct Ops {
     }
     static __device__ __forceinline__ void cell_update(E &e, const Ctx &cx, int c, uint32_t clear_bits, uint32_t xor_bits, Dirty &dt) {
 #pragma unroll
-        for (int k = 0; k < CPL; ++k)
-            if ((CPL == 1 || (c >> 6) == k) && cx.lane == (c & 63)) e.cell[k] = (e.cell[k] & ~clear_bits) ^ xor_bits;
+        for (int k = 0; k < CPL; ++k) {
+            const bool mine = (cx.lane + 64 * k) == c;
+            e.cell[k] = mine ? ((e.cell[k] & ~clear_bits) ^ xor_bits) : e.cell[k];
+        }
         dt.cells = 1;
     }
     // cooking_world.py:223-227 square_walkable: Floor (0) and Switch (3) always, Block (4) by its bit (only Blocks
     // ever carry CELL_WALK), everything else never
-    static __device__ __forceinline__ bool walkable(uint32_t cv) { return ((0x9u >> (cv & CELL_TYPE)) | (cv >> 6)) & 1u; }
+    static __device__ __forceinline__ bool walkable(uint32_t cv) { return (((0x9u >> (cv & CELL_TYPE)) | (cv >> 6)) & 1u) != 0u; }
     // statics that can hold objects: Counter 1, Deliversquare 2, Cutboard 5, Blender 6.  Interactions aimed at a Floor,
     // Switch or Block cell are no-ops in every case (nothing is ever placed there; the reference's agent-at-location
     // guard, cooking_world.py:116,140,158, only ever fires for such cells), so they return early on the type.
     static __device__ __forceinline__ bool holds_objects(uint32_t ty) { return (0x66u >> ty) & 1u; }
 
-    // ---- ballots over object lanes ----------------------------------------------------------------------
-    template <class F>
-    static __device__ __forceinline__ OM oballot(const E &e, F pred) {
+    // ---- lane masks over the object slots: one comparison each -------------------------------------------
+    static __device__ __forceinline__ OM m_d0(const E &e, uint32_t mask, uint32_t val) {       // (d0 & mask) == val
         OM m;
 #pragma unroll
-        for (int k = 0; k < OPL; ++k) m.w[k] = ballot(pred(e.d0[k], e.d1[k]));
+        for (int k = 0; k < OPL; ++k) m.w[k] = ballot((e.d0[k] & mask) == val);
         return m;
     }
-    static __device__ __forceinline__ OM content_of(const E &e, int plate) {   // Plate.content membership
-        uint32_t tag = (uint32_t)(plate + 1);
-        return oballot(e, [=](uint32_t a, uint32_t b) { return (a & D_ALIVE) && (b & 0xFFu) == tag; });
+    static __device__ __forceinline__ OM m_d0_any(const E &e, uint32_t bits) {                  // (d0 & bits) != 0
+        OM m;
+#pragma unroll
+        for (int k = 0; k < OPL; ++k) m.w[k] = ballot((e.d0[k] & bits) != 0u);
+        return m;
     }
+    static __device__ __forceinline__ OM m_d1(const E &e, uint32_t mask, uint32_t val) {       // (d1 & mask) == val
+        OM m;
+#pragma unroll
+        for (int k = 0; k < OPL; ++k) m.w[k] = ballot((e.d1[k] & mask) == val);
+        return m;
+    }
+    // Plate.content membership.  Invariant of every record (checked by cz_set_state / cz_load_layouts, kept by every
+    // operation below): a slot that is not alive carries d1 == 0, so a container tag (never 0) implies "alive".
+    static __device__ __forceinline__ OM content_of(const E &e, int plate) { return m_d1(e, 0xFFu, (uint32_t)(plate + 1)); }
+    static __device__ __forceinline__ OM outside_plates(const E &e) { return m_d1(e, 0xFFu, 0u); }   // (also dead slots: and it with alive ones)
     // static.content of a cell that holds objects == objects there that are not inside a plate (agents never stand on
     // such a cell, so nothing there is "held")
     static __device__ __forceinline__ OM direct_at(const E &e, uint32_t xy) {
-        return oballot(e, [=](uint32_t a, uint32_t b) { return (a & (D_ALIVE | 0xFFFFu)) == (D_ALIVE | xy) && (b & 0xFFu) == 0; });
+        return m_d0(e, D_ALIVE | 0xFFFFu, D_ALIVE | xy) & outside_plates(e);
     }
     // Object.move_to / Plate.move_to (abstract_classes.py:20, world_objects.py:393-396): slot s and, when it is a
     // plate, everything inside it
     static __device__ __forceinline__ void move_obj(E &e, const Ctx &cx, int s, uint32_t xy) {
-        uint32_t tag = (uint32_t)(s + 1);
+        OM m = content_of(e, s);
+        m.set(s);
 #pragma unroll
-        for (int k = 0; k < OPL; ++k) {
-            bool me = (cx.lane + 64 * k) == s || ((e.d0[k] & D_ALIVE) && (e.d1[k] & 0xFFu) == tag);
-            if (me) e.d0[k] = (e.d0[k] & 0xFFFF0000u) | xy;
-        }
+        for (int k = 0; k < OPL; ++k) e.d0[k] = lanes(m.w[k]) ? ((e.d0[k] & 0xFFFF0000u) | xy) : e.d0[k];
     }
     static __device__ __forceinline__ void slot_or(E &e, const Ctx &cx, int s, uint32_t bits) {
 #pragma unroll
-        for (int k = 0; k < OPL; ++k)
-            if (cx.lane + 64 * k == s) e.d0[k] |= bits;
+        for (int k = 0; k < OPL; ++k) {
+            const bool mine = (cx.lane + 64 * k) == s;
+            e.d0[k] = mine ? (e.d0[k] | bits) : e.d0[k];
+        }
     }
     // Plate.add_content (world_objects.py:398-406): append s to plate p: every item free=False, the new last True
     static __device__ __forceinline__ void plate_add(E &e, const Ctx &cx, int p, int s, int cnt) {
-        uint32_t tag = (uint32_t)(p + 1);
+        const uint32_t tag = (uint32_t)(p + 1);
+        const OM inside = content_of(e, p);
 #pragma unroll
         for (int k = 0; k < OPL; ++k) {
-            if ((e.d0[k] & D_ALIVE) && (e.d1[k] & 0xFFu) == tag) e.d0[k] &= ~D_FREE;
-            if (cx.lane + 64 * k == s) {
-                e.d1[k] = tag | ((uint32_t)cnt << 8);
-                e.d0[k] |= D_FREE;
-            }
+            const bool mine = (cx.lane + 64 * k) == s;
+            const uint32_t d = lanes(inside.w[k]) ? (e.d0[k] & ~D_FREE) : e.d0[k];
+            e.d0[k] = mine ? (d | D_FREE) : d;
+            e.d1[k] = mine ? (tag | ((uint32_t)cnt << 8)) : e.d1[k];
         }
     }
 
     // One agent's view while it acts (uniform scalars, written back by the caller)
-    struct Me { int x, y, o, h; };
+    struct Me { uint32_t xy; int h; };
 
-    // record that the object with dyn0 word `w` moved; a plate drags its content along -> anything
+    // record that the object with dyn0 word `w` moved: bit 4 * class + state of dt.kinds (a plate drags its content
+    // along: step_env widens a set with a Plate bit to "anything")
     static __device__ __forceinline__ void touch(Dirty &dt, uint32_t w) {
-        const uint32_t cls = (w >> 16) & 0xFFu;
         dt.touched = 1;
-        dt.kinds |= (cls == PLATE) ? ~0ull : (1ull << (4u * cls + ((w >> 25) & 3u)));
+        dt.kinds |= 1ull << (((w >> 14) & 0x3Cu) | ((w >> 25) & 3u));
     }
     // ... or changed from `before` to `after` (chopped, mashed, created)
     static __device__ __forceinline__ void touch_change(Dirty &dt, uint32_t before, uint32_t after) {
@@ -316,18 +346,17 @@ struct Ops {
     }
 
     // cooking_world.py:243-261 attempt_merge (first matching branch only, no fall-through on refusal).
-    // dyn = objects at the target cell, sv = its cell byte, (lx, ly) the cell
-    static __device__ __forceinline__ void attempt_merge(E &e, const Ctx &cx, Me &me, const OM &dyn, int lx, int ly, int c,
+    // dyn = objects at the target cell, sv = its cell byte, lxy the cell's x | y << 8, c its index
+    static __device__ __forceinline__ void attempt_merge(E &e, const Ctx &cx, Me &me, const OM &dyn, uint32_t lxy, int c,
                                                          uint32_t sv, Dirty &dt) {
-        const uint32_t lxy = (uint32_t)lx | ((uint32_t)ly << 8);
         const int held = me.h;
         const uint32_t hw = slot_d0(e, held);
         const uint32_t hcls = (hw >> 16) & 0xFF;
-        OM plates = dyn & oballot(e, [](uint32_t a, uint32_t) { return (a & 0xFF0000u) == (PLATE << 16); });
-        int np = plates.count();
+        const OM plates = dyn & m_d0(e, 0xFF0000u, PLATE << 16);
+        const int np = plates.count();
         if (np == 1) {
-            int p = plates.first();
-            int cnt = content_of(e, p).count();
+            const int p = plates.first();
+            const int cnt = content_of(e, p).count();
             // Plate.accepts world_objects.py:408-409: Food, done(), < 64 items
             if (hcls != PLATE && (hw & D_DONE) && cnt < 64) {
                 plate_add(e, cx, p, held, cnt);
@@ -336,18 +365,18 @@ struct Ops {
                 touch(dt, hw);
             }
         } else if (hcls == PLATE && dyn.any()) {
-            int o = dyn.last();                                   // pick_index = -1
-            uint32_t ow = slot_d0(e, o);
-            int cnt = content_of(e, held).count();
+            const int o = dyn.last();                             // pick_index = -1
+            const uint32_t ow = slot_d0(e, o);
+            const int cnt = content_of(e, held).count();
             if ((ow & 0xFF0000u) != (PLATE << 16) && (ow & D_DONE) && cnt < 64) {
                 plate_add(e, cx, held, o, cnt);
-                move_obj(e, cx, o, (uint32_t)me.x | ((uint32_t)me.y << 8));
+                move_obj(e, cx, o, me.xy);
                 touch(dt, ow);
                 // static_object.content.remove(o) is implicit: o now carries a container tag
             }
         } else {
-            int ncontent = (dyn & oballot(e, [](uint32_t, uint32_t b) { return (b & 0xFFu) == 0; })).count();
-            uint32_t ty = sv & CELL_TYPE;
+            const int ncontent = (dyn & outside_plates(e)).count();
+            const uint32_t ty = sv & CELL_TYPE;
             bool ok = false;
             if (ty == COUNTER || ty == DELIVERSQUARE) {                            // world_objects.py:64-66,107-108
                 ok = ncontent < 1;
@@ -367,15 +396,15 @@ struct Ops {
         }
     }
 
-    // cooking_world.py:114-136 resolve_primary_interaction on cell (lx, ly) = c whose byte is sv (a cell that holds objects)
-    static __device__ __forceinline__ void primary(E &e, const Ctx &cx, Me &me, int lx, int ly, int c, uint32_t sv, const OM &dyn,
+    // cooking_world.py:114-136 resolve_primary_interaction on the cell lxy = c whose byte is sv (a cell that holds objects)
+    static __device__ __forceinline__ void primary(E &e, const Ctx &cx, Me &me, uint32_t lxy, int c, uint32_t sv, const OM &dyn,
                                                    Dirty &dt) {
         if (me.h < 0) {
             if (!dyn.any()) return;
             dt.interacted = 1;
-            OM direct = dyn & oballot(e, [](uint32_t, uint32_t b) { return (b & 0xFFu) == 0; });
-            int ncontent = direct.count();
-            uint32_t ty = sv & CELL_TYPE;
+            const OM direct = dyn & outside_plates(e);
+            const int ncontent = direct.count();
+            const uint32_t ty = sv & CELL_TYPE;
             // static_object.releases() with its side effects: world_objects.py:117-118,275-278,340-346
             bool rel = true;
             if (ty == DELIVERSQUARE) rel = false;
@@ -386,63 +415,63 @@ struct Ops {
                 if (rel && ncontent - 1 == 0 && (sv & CELL_READY)) cell_update(e, cx, c, CELL_READY, 0, dt);
             }
             if (rel) {
-                OM fr = dyn & oballot(e, [](uint32_t a, uint32_t) { return (a & D_FREE) != 0; });
-                int grab = fr.any() ? fr.first() : dyn.last();
+                const OM fr = dyn & m_d0_any(e, D_FREE);
+                const int grab = fr.any() ? fr.first() : dyn.last();
                 if (direct.test(grab)) {                        // object_to_grab in static_object.content
                     me.h = grab;                                // Agent.grab world_objects.py:785-787
                     touch(dt, slot_d0(e, grab));
-                    move_obj(e, cx, grab, (uint32_t)me.x | ((uint32_t)me.y << 8));
+                    move_obj(e, cx, grab, me.xy);
                 }
             }
         } else {
             dt.interacted = 1;
-            attempt_merge(e, cx, me, dyn, lx, ly, c, sv, dt);
+            attempt_merge(e, cx, me, dyn, lxy, c, sv, dt);
         }
     }
 
     // cooking_world.py:138-154 resolve_interaction_pick_up_special (scheme1)
     static __device__ __forceinline__ void pick_up_special(E &e, const Ctx &cx, Me &me, const OM &dyn, Dirty &dt) {
         if (me.h >= 0 || !dyn.any()) return;
-        OM plates = dyn & oballot(e, [](uint32_t a, uint32_t) { return (a & 0xFF0000u) == (PLATE << 16); });
+        const OM plates = dyn & m_d0(e, 0xFF0000u, PLATE << 16);
         if (plates.count() != 1) return;
-        int p = plates.first();
-        OM cm = content_of(e, p);
-        int cnt = cm.count();
+        const int p = plates.first();
+        const OM cm = content_of(e, p);
+        const int cnt = cm.count();
         if (cnt == 0) return;                               // IndexError swallowed
-        uint32_t want = (uint32_t)(cnt - 1);
-        OM lastm = cm & oballot(e, [=](uint32_t, uint32_t b) { return ((b >> 8) & 0xFFu) == want; });
-        int s = lastm.first();
+        const OM lastm = cm & m_d1(e, 0xFF00u, (uint32_t)(cnt - 1) << 8);
+        const int s = lastm.first();
 #pragma unroll
-        for (int k = 0; k < OPL; ++k)
-            if (cx.lane + 64 * k == s) e.d1[k] = 0;        // content.pop(-1)
+        for (int k = 0; k < OPL; ++k) {
+            const bool mine = (cx.lane + 64 * k) == s;
+            e.d1[k] = mine ? 0u : e.d1[k];                 // content.pop(-1)
+        }
         me.h = s;
         touch(dt, slot_d0(e, s));
-        move_obj(e, cx, s, (uint32_t)me.x | ((uint32_t)me.y << 8));
+        move_obj(e, cx, s, me.xy);
         dt.interacted = 1;
     }
 
     // cooking_world.py:156-170 resolve_execute_action; Cutboard.action world_objects.py:250-269;
     // ChopFood.chop abstract_classes.py:250-254; Bread.chop world_objects.py:738-745; Blender.action :356-360
-    static __device__ __forceinline__ void execute(E &e, const Ctx &cx, int lx, int ly, int c, uint32_t sv, const OM &dyn, Dirty &dt) {
+    static __device__ __forceinline__ void execute(E &e, const Ctx &cx, uint32_t lxy, int c, uint32_t sv, const OM &dyn, Dirty &dt) {
         const uint32_t ty = sv & CELL_TYPE;
         if (ty == CUTBOARD) {
             if (!(sv & CELL_READY)) return;
-            const uint32_t lxy = (uint32_t)lx | ((uint32_t)ly << 8);
-            OM fresh = dyn & oballot(e, [](uint32_t a, uint32_t b) { return (b & 0xFFu) == 0 && !(a & D_CHOPPED); });
-            int f = fresh.first();                          // first content item whose chop() executes
+            const OM fresh = dyn & outside_plates(e) & m_d0(e, D_CHOPPED, 0u);
+            const int f = fresh.first();                    // first content item whose chop() executes
             if (f < 0) return;                              // reference falls off Cutboard.action (TypeError); unreachable
-            uint32_t fw = slot_d0(e, f);
+            const uint32_t fw = slot_d0(e, f);
             slot_or(e, cx, f, D_CHOPPED);
             if ((fw & 0xFF0000u) == (BREAD << 16)) {
                 // the clone: first not-alive Bread slot (head-room follows the originals), born chopped and free
-                OM spare = oballot(e, [](uint32_t a, uint32_t) { return (a & (D_ALIVE | 0xFF0000u)) == (BREAD << 16); });
-                int n = spare.first();
+                const OM spare = m_d0(e, D_ALIVE | 0xFF0000u, BREAD << 16);
+                const int n = spare.first();
 #pragma unroll
-                for (int k = 0; k < OPL; ++k)
-                    if (n >= 0 && cx.lane + 64 * k == n) {
-                        e.d0[k] = lxy | (BREAD << 16) | D_ALIVE | D_CHOPPED | D_FREE;
-                        e.d1[k] = 0;
-                    }
+                for (int k = 0; k < OPL; ++k) {
+                    const bool mine = (cx.lane + 64 * k) == n;      // n == -1 (no head-room left): nobody
+                    e.d0[k] = mine ? (lxy | (BREAD << 16) | D_ALIVE | D_CHOPPED | D_FREE) : e.d0[k];
+                    e.d1[k] = mine ? 0u : e.d1[k];
+                }
             }
             cell_update(e, cx, c, CELL_READY, 0, dt);
             touch_change(dt, fw, fw | D_CHOPPED);               // (a Bread clone is a chopped Bread too)
@@ -470,19 +499,24 @@ struct Ops {
         return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
     }
 
-    static __device__ __forceinline__ void perform_agent_actions(E &e, const Ctx &cx, uint32_t act, Dirty &dt) {
+    static __device__ __forceinline__ void perform_agent_actions(E &e, const Ctx &cx, uint32_t act_raw, Dirty &dt) {
         const uint32_t W = (uint32_t)cx.W, H = (uint32_t)cx.H;
-        uint32_t x = e.agw & 0xFFu, y = (e.agw >> 8) & 0xFFu, o = (e.agw >> 16) & 0xFFu;
+        const uint32_t agw = e.agw;                                        // 0 on lanes >= NA
+        const uint32_t x = agw & 0xFFu, y = (agw >> 8) & 0xFFu, xy = agw & 0xFFFFu;
         // a negative action = the agent is despawned: it is not in the list world_step acts on (cooking_world.py:105-108:
         // no turn, no move, no part in the collision filter) but keeps its place in the world
-        const bool live = (int32_t)act >= 0;
-        act = live ? (act & 7u) : 0u;
-        if (act - 1u < 4u) o = act;                                         // change_orientation before any filtering
-        uint32_t tx = x + ((DX_TABLE >> (2u * act)) & 3u) - 1u, ty = y + ((DY_TABLE >> (2u * act)) & 3u) - 1u;
-        // check_inbounds (0 and 5 pass; 6 and 7 aim at the own cell, always inside); negative wraps to huge
-        if (tx >= W || ty >= H) { act = 0; tx = x; ty = y; }
-        const uint32_t own = y * W + x;
-        uint32_t c = ty * W + tx;
+        const uint64_t agent_m = ballot((int32_t)act_raw >= 0) & ((1ull << NA) - 1ull);
+        const uint32_t act0 = lanes(agent_m) ? (act_raw & 7u) : 0u;        // (lanes >= NA carry a copy of the last agent's action)
+        const uint32_t sh = 2u * act0;
+        const uint32_t tx = x + ((DX_TABLE >> sh) & 3u) - 1u, ty = y + ((DY_TABLE >> sh) & 3u) - 1u;   // negative wraps to huge
+        // change_orientation before any filtering (lanes that are not agents have action 0 here: their word stays 0)
+        uint32_t ag = lanes(ballot(act0 - 1u < 4u)) ? ((agw & 0xFF00FFFFu) | (act0 << 16)) : agw;
+        // check_inbounds (0 and 5 pass; 6 and 7 aim at the own cell, always inside): outside -> action 0
+        const uint64_t inb_m = ballot(tx < W) & ballot(ty < H);
+        const uint32_t own = __umul24(y, W) + x;
+        uint32_t txy = lanes(inb_m) ? (tx | (ty << 8)) : xy;
+        uint32_t c = lanes(inb_m) ? (__umul24(ty, W) + tx) : own;
+        uint64_t moving_m = ballot(act0 != 0u) & inb_m;                    // lanes whose action is not 0 (any more)
         // walkable cells and Switch cells as wave-uniform cell sets: what an agent lane needs to know about its target
         // and its own cell is a bit test (the cell bytes live in the cell lanes; a ballot is cheaper than two LDS permutes)
         CM walk_set, switch_set;
@@ -491,79 +525,90 @@ struct Ops {
             walk_set.w[k] = ballot(walkable(e.cell[k]));
             switch_set.w[k] = ballot((e.cell[k] & CELL_TYPE) == SWITCH);
         }
-        const bool wk = cell_bit(walk_set, c);
+        const uint64_t wk_m = ballot(cell_bit(walk_set, c));
         // check_collisions: an agent is cancelled iff its end cell equals another agent's end cell and its own
         // target was walkable.  Non-agents carry a value nobody else has.
-        const bool is_agent = cx.lane < NA && live;
-        const uint32_t exy = !is_agent ? (0xFFFF0000u | (uint32_t)cx.lane) : (wk ? (tx | (ty << 8)) : (x | (y << 8)));
-        // (every DPP move runs with all lanes enabled: a lane switched off by a short-circuit would read as 0 elsewhere)
-        bool clash = false;
-        if (NA == 2) clash = exy == quad<0xB1>(exy);                                            // lanes 0 <-> 1
-        if (NA > 2) {                                                                           // the other three lanes of the quad
-            const uint32_t r1 = quad<0x39>(exy), r2 = quad<0x4E>(exy), r3 = quad<0x93>(exy);
-            clash = (exy == r1) | (exy == r2) | (exy == r3);
+        if (NA > 1) {
+            const uint32_t endxy = lanes(wk_m) ? txy : xy;
+            const uint32_t exy = lanes(agent_m) ? endxy : (0xFFFF0000u | (uint32_t)cx.lane);
+            // (every DPP move runs with all lanes enabled: a lane switched off by a short-circuit would read as 0 elsewhere)
+            uint64_t clash_m;
+            if (NA == 2) {
+                clash_m = ballot(exy == quad<0xB1>(exy));                                       // lanes 0 <-> 1
+            } else {                                                                            // the other three lanes of the quad
+                const uint32_t r1 = quad<0x39>(exy), r2 = quad<0x4E>(exy), r3 = quad<0x93>(exy);
+                clash_m = ballot(exy == r1) | ballot(exy == r2) | ballot(exy == r3);
+            }
+            const uint64_t cancel_m = clash_m & wk_m & moving_m;           // now "walks" onto its own cell, with action 0
+            txy = lanes(cancel_m) ? xy : txy;
+            c = lanes(cancel_m) ? own : c;
+            moving_m &= ~cancel_m;
         }
-        if (NA > 1 && clash && wk && act != 0u) { act = 0; tx = x; ty = y; c = own; }   // now "walks" onto its own cell
-        if (is_agent) e.agw = (e.agw & 0xFF00FFFFu) | (o << 16);              // lanes >= NA stay 0 (unused agent words)
+        const uint32_t act = lanes(moving_m) ? act0 : 0u;                  // the action after both filters (scheme1 looks at it)
         // ---- execution.  The reference resolves agents one after the other (action_scheme3.py:15-16), but a walking
         // agent only changes its own position, the position of what it carries and Switch bits, while an interacting
         // agent only changes objects on cells that hold objects, its own hands and READY/TOGGLE bits; collisions were
         // resolved above.  The two kinds of effects commute, so all walking happens at once (lane a = agent a) and
         // only the interacting agents are taken serially, in index order.
-        const bool is_walk_act = SCHEME == 3 || (act - 1u < 4u);
-        const bool walks = is_agent && is_walk_act && wk;                 // action_scheme3.py:26-34 (scheme3: also action 0)
-        const uint32_t txy = tx | (ty << 8);
-        if (walks) e.agw = (e.agw & 0xFFFF0000u) | txy;                    // Agent.move_to world_objects.py:793-796
-        uint64_t drag = ballot(walks && act != 0u && (e.agw >> 24) != 0u); // ... which drags what the agent holds
-        while (drag) {
-            const int a = __ffsll((unsigned long long)drag) - 1;
-            drag &= drag - 1;
-            const uint32_t A = rdl(e.agw, a);
-            move_obj(e, cx, (int)(A >> 24) - 1, A & 0xFFFFu);
+        uint64_t walks_m = agent_m & wk_m;                                 // action_scheme3.py:26-34 (scheme3: also action 0)
+        if (SCHEME != 3) walks_m &= ballot(act - 1u < 4u);
+        ag = lanes(walks_m) ? ((ag & 0xFFFF0000u) | txy) : ag;             // Agent.move_to world_objects.py:793-796
+        e.agw = ag;
+        uint64_t drag = walks_m & moving_m & ballot(ag > 0x00FFFFFFu);     // ... which drags what the agent holds
+        if (drag) {
             dt.moved = 1;
+            do {
+                const int a = __builtin_ctzll(drag);
+                drag &= drag - 1;
+                const uint32_t A = rdl(e.agw, a);
+                move_obj(e, cx, (int)(A >> 24) - 1, A & 0xFFFFu);
+            } while (drag);
         }
-        uint64_t press = ballot(walks && cell_bit(switch_set, c));         // Switch.add_content world_objects.py:159-163
-        while (press) {
-            const int a = __ffsll((unsigned long long)press) - 1;
-            press &= press - 1;
-            cell_update(e, cx, (int)rdl(c, a), 0, CELL_ACTIVE, dt);
+        uint64_t press = walks_m & ballot(cell_bit(switch_set, c));        // Switch.add_content world_objects.py:159-163
+        if (press) {
             dt.pressed = 1;
+            do {
+                const int a = __builtin_ctzll(press);
+                press &= press - 1;
+                cell_update(e, cx, (int)rdl(c, a), 0, CELL_ACTIVE, dt);
+            } while (press);
         }
-        uint64_t inter = ballot(is_agent && !walks && (SCHEME == 3 ? act != 0u : act >= 5u));
+        uint64_t inter = agent_m & ~walks_m & (SCHEME == 3 ? moving_m : ballot(act >= 5u));
         while (inter) {
-            const int a = __ffsll((unsigned long long)inter) - 1;
+            const int a = __builtin_ctzll(inter);
             inter &= inter - 1;
             const uint32_t A = rdl(e.agw, a);
-            const int ac = (int)rdl(act, a);
-            Me me{(int)(A & 0xFFu), (int)((A >> 8) & 0xFFu), (int)((A >> 16) & 0xFFu), (int)(A >> 24) - 1};
+            Me me{A & 0xFFFFu, (int)(A >> 24) - 1};
             // the cell in front (scheme3: the bumped cell; scheme1: by orientation, may be off-grid)
-            int fx, fy;
+            uint32_t fxy;
+            int fc;
             bool ok = true;
             if (SCHEME == 3) {
-                const uint32_t lxy = rdl(txy, a);
-                fx = (int)(lxy & 0xFFu); fy = (int)(lxy >> 8);
+                fxy = rdl(txy, a);
+                fc = (int)rdl(c, a);
             } else {
-                fx = me.x + (int)((DX_TABLE >> (2 * me.o)) & 3u) - 1;
-                fy = me.y + (int)((DY_TABLE >> (2 * me.o)) & 3u) - 1;
-                ok = (uint32_t)fx < W && (uint32_t)fy < H;              // reference: IndexError; build: no-op
+                const uint32_t o = (A >> 16) & 0xFFu;
+                const uint32_t fx = (A & 0xFFu) + ((DX_TABLE >> (2u * o)) & 3u) - 1u;
+                const uint32_t fy = ((A >> 8) & 0xFFu) + ((DY_TABLE >> (2u * o)) & 3u) - 1u;
+                ok = fx < W && fy < H;                                      // reference: IndexError; build: no-op
+                fxy = fx | (fy << 8);
+                fc = (int)(fy * W + fx);
             }
-            const int fc = fy * cx.W + fx;
-            const uint32_t sv = ok ? cell_at(e, fc) : 0u;               // READY / TOGGLE may have been changed by an earlier agent
+            const uint32_t sv = ok ? cell_at(e, fc) : 0u;                   // READY / TOGGLE may have been changed by an earlier agent
             if (ok && holds_objects(sv & CELL_TYPE)) {
-                const uint32_t fxy = (uint32_t)fx | ((uint32_t)fy << 8);
                 // get_objects_at(location, DynamicObject) cooking_world.py:232-241 as a slot mask
-                OM dyn = oballot(e, [=](uint32_t w, uint32_t) { return (w & (D_ALIVE | 0xFFFFu)) == (D_ALIVE | fxy); });
+                const OM dyn = m_d0(e, D_ALIVE | 0xFFFFu, D_ALIVE | fxy);
                 if (SCHEME == 3) {
                     // action_scheme3.py:37-43: ActionObject with a not-done item -> execute, else primary
                     bool exec = false;
-                    if ((sv & CELL_TYPE) >= CUTBOARD)
-                        exec = (dyn & oballot(e, [](uint32_t w, uint32_t) { return !(w & D_DONE); })).any();
-                    if (exec) execute(e, cx, fx, fy, fc, sv, dyn, dt);
-                    else primary(e, cx, me, fx, fy, fc, sv, dyn, dt);
+                    if ((sv & CELL_TYPE) >= CUTBOARD) exec = (dyn & m_d0(e, D_DONE, 0u)).any();
+                    if (exec) execute(e, cx, fxy, fc, sv, dyn, dt);
+                    else primary(e, cx, me, fxy, fc, sv, dyn, dt);
                 } else {
-                    if (ac == 5) primary(e, cx, me, fx, fy, fc, sv, dyn, dt);
+                    const int ac = (int)rdl(act, a);
+                    if (ac == 5) primary(e, cx, me, fxy, fc, sv, dyn, dt);
                     else if (ac == 6) pick_up_special(e, cx, me, dyn, dt);
-                    else execute(e, cx, fx, fy, fc, sv, dyn, dt);
+                    else execute(e, cx, fxy, fc, sv, dyn, dt);
                 }
                 e.agw = wrl((A & 0x00FFFFFFu) | ((uint32_t)((me.h + 1) & 0xFF) << 24), a, e.agw);   // only the hands can change
             }
@@ -583,12 +628,12 @@ struct Ops {
             running.clear(c);
             uint32_t y = (uint32_t)c / (uint32_t)cx.W;
             uint32_t xy = ((uint32_t)c - y * (uint32_t)cx.W) | (y << 8);
-            OM content = direct_at(e, xy);
+            const OM content = direct_at(e, xy);
             if (content.any()) {
+                const OM fresh = content & m_d0(e, D_DONE, 0u);
 #pragma unroll
-                for (int k = 0; k < OPL; ++k)
-                    if (((content.w[k] >> cx.lane) & 1) && !(e.d0[k] & D_DONE)) e.d0[k] |= D_MASHED;
-                OM mashed = content & oballot(e, [](uint32_t a, uint32_t) { return (a & D_MASHED) != 0; });
+                for (int k = 0; k < OPL; ++k) e.d0[k] = lanes(fresh.w[k]) ? (e.d0[k] | D_MASHED) : e.d0[k];
+                const OM mashed = content & m_d0_any(e, D_MASHED);
                 if (mashed.count() == content.count()) cell_update(e, cx, c, CELL_READY | CELL_TOGGLE, 0, dt);
                 dt.touched = 1;
                 dt.statechg = 1;
@@ -605,10 +650,9 @@ struct Ops {
         if (dt.interacted) {
             // The pass over the statics can only change something if an object lying directly on a static is not free, or
             // if a Bread and its clone may share a Cutboard; both are rare, so test for them first (exact for any state).
-            const OM unfree = oballot(e, [](uint32_t a, uint32_t b) { return (a & (D_ALIVE | D_FREE)) == D_ALIVE && (b & 0xFFu) == 0; });
-            const OM breads = oballot(e, [](uint32_t a, uint32_t b) {
-                return (a & (D_ALIVE | D_CHOPPED | 0xFF0000u)) == (D_ALIVE | D_CHOPPED | (BREAD << 16)) && (b & 0xFFu) == 0;
-            });
+            const OM outside = outside_plates(e);
+            const OM unfree = m_d0(e, D_ALIVE | D_FREE, D_ALIVE) & outside;
+            const OM breads = m_d0(e, D_ALIVE | D_CHOPPED | 0xFF0000u, D_ALIVE | D_CHOPPED | (BREAD << 16)) & outside;
             if (unfree.any() || breads.count() > 1) {
                 OM held = OM::zero();
 #pragma unroll
@@ -617,60 +661,74 @@ struct Ops {
                     if (hs >= 0) held.set(hs);
                 }
                 // every object lying directly on a static is the last (only) item of that static's content ...
+                const OM on_static = (m_d0_any(e, D_ALIVE) & outside).andnot(held);
 #pragma unroll
-                for (int k = 0; k < OPL; ++k) {
-                    bool on_static = (e.d0[k] & D_ALIVE) && (e.d1[k] & 0xFFu) == 0 && !((held.w[k] >> cx.lane) & 1);
-                    if (on_static) e.d0[k] |= D_FREE;
-                }
+                for (int k = 0; k < OPL; ++k) e.d0[k] = lanes(on_static.w[k]) ? (e.d0[k] | D_FREE) : e.d0[k];
                 // ... except on a Cutboard that carries a Bread and its clone (the only way a static gets two items,
                 // world_objects.py:738-745): both are chopped Breads lying directly on the same cell
-                OM twins = oballot(e, [](uint32_t a, uint32_t b) {
-                    return (a & (D_ALIVE | D_CHOPPED | 0xFF0000u)) == (D_ALIVE | D_CHOPPED | (BREAD << 16)) && (b & 0xFFu) == 0;
-                }).andnot(held);
+                const OM twins = breads.andnot(held);
                 if (twins.count() > 1) {
                     OM it = twins;
                     while (it.any()) {
                         const int s = it.first();
                         const uint32_t xy = slot_d0(e, s) & 0xFFFFu;
-                        OM content = direct_at(e, xy).andnot(held);
+                        const OM content = direct_at(e, xy).andnot(held);
                         it = it.andnot(content);
                         if (content.count() > 1) {
-                            const int last = content.last();
+                            OM rest = content;
+                            rest.clear(content.last());
 #pragma unroll
-                            for (int k = 0; k < OPL; ++k)
-                                if (((content.w[k] >> cx.lane) & 1) && (cx.lane + 64 * k) != last) e.d0[k] &= ~D_FREE;
+                            for (int k = 0; k < OPL; ++k) e.d0[k] = lanes(rest.w[k]) ? (e.d0[k] & ~D_FREE) : e.d0[k];
                         }
                     }
                 }
             }
             // inside a plate: free iff last appended
-            OM inside = oballot(e, [](uint32_t a, uint32_t b) { return (a & D_ALIVE) && (b & 0xFFu) != 0; });
+            OM inside = m_d0_any(e, D_ALIVE).andnot(outside);
             while (inside.any()) {
                 const int s = inside.first();
-                uint32_t b1 = 0;
-#pragma unroll
-                for (int k = 0; k < OPL; ++k)
-                    if (OPL == 1 || (s >> 6) == k) b1 = rdl(e.d1[k], s & 63);
-                const int p = (int)(b1 & 0xFFu) - 1;
-                OM content = content_of(e, p);
+                const int p = (int)(slot_d1(e, s) & 0xFFu) - 1;
+                const OM content = content_of(e, p);
                 inside = inside.andnot(content);
                 const int cnt = content.count();
+                const OM lastone = content & m_d1(e, 0xFF00u, (uint32_t)(cnt - 1) << 8);
+                const OM others = content.andnot(lastone);
 #pragma unroll
-                for (int k = 0; k < OPL; ++k)
-                    if ((content.w[k] >> cx.lane) & 1) {
-                        bool lastone = ((e.d1[k] >> 8) & 0xFFu) == (uint32_t)(cnt - 1);
-                        e.d0[k] = lastone ? (e.d0[k] | D_FREE) : (e.d0[k] & ~D_FREE);
-                    }
+                for (int k = 0; k < OPL; ++k) {
+                    const uint32_t d = lanes(lastone.w[k]) ? (e.d0[k] | D_FREE) : e.d0[k];
+                    e.d0[k] = lanes(others.w[k]) ? (d & ~D_FREE) : d;
+                }
             }
         }
         // Switch.process_linked_objects world_objects.py:165-169 -> Block.switch_state :215-216 (all linked)
         if (dt.pressed) {
 #pragma unroll
-            for (int k = 0; k < CPL; ++k)
-                if ((e.cell[k] & CELL_TYPE) == BLOCK) e.cell[k] ^= CELL_WALK;
+            for (int k = 0; k < CPL; ++k) {
+                const bool blk = (e.cell[k] & CELL_TYPE) == BLOCK;
+                e.cell[k] = blk ? (e.cell[k] ^ CELL_WALK) : e.cell[k];
+            }
         }
     }
 
+    // objects a recipe node's class / state conditions accept: class and alive in one comparison, the accept mask over the
+    // state index chopped | mashed << 1 in another
+    static __device__ __forceinline__ OM node_matches(const E &e, uint32_t cval, uint32_t acc) {
+        OM m;
+#pragma unroll
+        for (int k = 0; k < OPL; ++k)
+            m.w[k] = ballot((e.d0[k] & 0x01FF0000u) == cval) & ballot(((acc >> ((e.d0[k] >> 25) & 3u)) & 1u) != 0u);
+        return m;
+    }
+    // ... of which those that sit on a cell of the set `allow`
+    static __device__ __forceinline__ OM on_cells(const E &e, const Ctx &cx, const OM &cand, const CM &allow) {
+        OM m;
+#pragma unroll
+        for (int k = 0; k < OPL; ++k) {
+            const uint32_t mycell = __umul24((e.d0[k] >> 8) & 0xFFu, (uint32_t)cx.W) + (e.d0[k] & 0xFFu);
+            m.w[k] = cand.w[k] & ballot(cell_bit(allow, mycell));
+        }
+        return m;
+    }
     // recipe.py:77-104 update_recipe_state for one recipe graph; returns the marks byte (bit j = node j marked).
     // Device node word (built by cz_load_recipes from the host table):
     //   bits 0..7   child mask                 bit 8       counts in the goal sum
@@ -692,12 +750,11 @@ struct Ops {
             const uint32_t children = w & 0xFFu;
             if ((marks & children) != children) continue;                 // all(contains.marked)
             const uint32_t cval = (w & 0x00FF0000u) | D_ALIVE, acc = (w >> 24) & 0xFu;
-            auto matches = [=](uint32_t a) { return (a & 0x01FF0000u) == cval && ((acc >> ((a >> 25) & 3u)) & 1u) != 0u; };
             CM here = CM::zero();
             bool any;
             if (children == 0u && !(w & 0x200u)) {
                 // leaf of a dynamic class (the common case): no location constraint
-                OM m = oballot(e, [=](uint32_t a, uint32_t) { return matches(a); });
+                OM m = node_matches(e, cval, acc);
                 any = m.any();
                 while (j > 0 && m.any()) {                                 // record where the matches are (a handful at most)
                     const int s = m.first();
@@ -724,21 +781,10 @@ struct Ops {
                     const uint32_t cls = (w >> 10) & 7u;
 #pragma unroll
                     for (int k = 0; k < CPL; ++k)
-                        here.w[k] = ballot((e.cell[k] & CELL_TYPE) == cls && (cx.lane + 64 * k) < cx.C) & allow.w[k];
+                        here.w[k] = ballot((e.cell[k] & CELL_TYPE) == cls) & ballot((cx.lane + 64 * k) < cx.C) & allow.w[k];
                     any = here.any();
                 } else {                                                  // a dynamic class with children
-                    OM m;
-#pragma unroll
-                    for (int k = 0; k < OPL; ++k) {
-                        const uint32_t mycell = ((e.d0[k] >> 8) & 0xFFu) * (uint32_t)cx.W + (e.d0[k] & 0xFFu);
-                        uint64_t wsel = allow.w[0];
-                        if (CPL > 1) {
-#pragma unroll
-                            for (int q = 1; q < CPL; ++q)
-                                if ((mycell >> 6) == (uint32_t)q) wsel = allow.w[q];
-                        }
-                        m.w[k] = ballot(matches(e.d0[k]) && ((wsel >> (mycell & 63)) & 1));
-                    }
+                    OM m = on_cells(e, cx, node_matches(e, cval, acc), allow);
                     any = m.any();
                     while (j > 0 && m.any()) {
                         const int s = m.first();
@@ -771,7 +817,6 @@ struct Ops {
             const uint32_t w = rfl(row[1 + 2 * j]), children = rfl(row[2 + 2 * j]) & 0xFFFFu;
             if ((marks & children) != children) continue;                 // all(contains.marked)
             const uint32_t cval = (w & 0x00FF0000u) | D_ALIVE, acc = (w >> 24) & 0xFu;
-            auto matches = [=](uint32_t a) { return (a & 0x01FF0000u) == cval && ((acc >> ((a >> 25) & 3u)) & 1u) != 0u; };
             CM allow;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) allow.w[q] = ~0ull;
@@ -790,18 +835,9 @@ struct Ops {
                 const uint32_t cls = (w >> 10) & 7u;
 #pragma unroll
                 for (int k = 0; k < CPL; ++k)
-                    here.w[k] = ballot((e.cell[k] & CELL_TYPE) == cls && (cx.lane + 64 * k) < cx.C) & allow.w[k];
+                    here.w[k] = ballot((e.cell[k] & CELL_TYPE) == cls) & ballot((cx.lane + 64 * k) < cx.C) & allow.w[k];
             } else if (w & 0x2000u) {                                     // a dynamic class
-                OM m;
-#pragma unroll
-                for (int k = 0; k < OPL; ++k) {
-                    const uint32_t mycell = ((e.d0[k] >> 8) & 0xFFu) * (uint32_t)cx.W + (e.d0[k] & 0xFFu);
-                    uint64_t wsel = allow.w[0];
-#pragma unroll
-                    for (int q = 1; q < CPL; ++q)
-                        if ((mycell >> 6) == (uint32_t)q) wsel = allow.w[q];
-                    m.w[k] = ballot(matches(e.d0[k]) && ((wsel >> (mycell & 63)) & 1));
-                }
+                OM m = on_cells(e, cx, node_matches(e, cval, acc), allow);
                 while (m.any()) {
                     const int sl = m.first();
                     m.clear(sl);

@@ -387,6 +387,7 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
     uint32_t after = before;
     o.myrew = cx.lane < NA ? P.reward_idle : 0.0;
     if (dt.moved & (uint32_t)P.walk_touches) { dt.touched = 1; dt.kinds = ~0ull; }
+    if (dt.kinds & 0xFull) dt.kinds = ~0ull;                        // a Plate moved: it drags its content along -> anything
     bool done = false;
     if (__builtin_expect(P.wide != 0, 0)) {
         // Wide recipe tables (a graph with more than 8 nodes in the book): no filters, every recipe of the env is

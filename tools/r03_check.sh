@@ -1,0 +1,10 @@
+#!/bin/bash
+# GPU box: quick parity subset + instruction counts per mode + same-box A/B bench of .ab/prev against this tree.
+# usage: bash tools/r03_check.sh TAG [pytest -k expression]
+TAG=${1:-x}; K=${2:-"parity or rollout or fuzz or api"}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r03
+python -m pytest tests -m gpu -x -q -k "$K" 2>&1 | tail -8 > gpurun_out/r03/tests_$TAG.log
+bash tools/interact_probe.sh > gpurun_out/r03/ip_$TAG.txt 2>&1
+if [ -d .ab/prev ]; then CZ_CHAIN=0 bash tools/ab_trees.sh .ab/prev . 2 > gpurun_out/r03/ab_$TAG.txt 2>&1; fi
+cat gpurun_out/r03/tests_$TAG.log gpurun_out/r03/ip_$TAG.txt gpurun_out/r03/ab_$TAG.txt
