@@ -143,6 +143,7 @@ struct cz_handle_s {
     cz_stats *d_stats_out = nullptr;
     unsigned long long *d_stats_part = nullptr;   // [256 chains][16 columns] between the two stages of the reduction
     double *d_lut = nullptr;
+    void *d_dump = nullptr;            // [N][4] doubles: where a one-step launch writes an output array the caller passed as NULL
     // staging for the host-pointer API
     int32_t *d_actions = nullptr;
     double *d_obs = nullptr;
@@ -313,6 +314,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     CREATE_CHK(hipMemsetAsync(h->d_stat_u, 0, N * SU_WORDS * 4, h->stream));
     CREATE_CHK(hipMemsetAsync(h->d_stat_f, 0, N * SF_WORDS * 8, h->stream));
     CREATE_CHK(hipMalloc(&h->d_stats_out, sizeof(cz_stats)));
+    CREATE_CHK(hipMalloc(&h->d_dump, N * MAX_AGENTS * sizeof(double)));
     CREATE_CHK(hipMalloc(&h->d_stats_part, (size_t)STAT_CHAINS * 16 * sizeof(unsigned long long)));
     CREATE_CHK(hipStreamSynchronize(h->stream));
     P.state = h->d_state; P.stat_u = h->d_stat_u; P.stat_f = h->d_stat_f;
@@ -323,8 +325,28 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
         for (int i = 0; i < 2 * P.W - 1; ++i) lut[i] = (double)(i - (P.W - 1)) / (double)P.W;
         for (int i = 0; i < 2 * P.H - 1; ++i) lut[LUT_Y0 + i] = (double)(i - (P.H - 1)) / (double)P.H;
         lut[LUT_ZERO] = 0.0; lut[LUT_ONE] = 1.0;
-        CREATE_CHK(hipMalloc(&h->d_lut, sizeof lut));
+        // flag truth tables (cz_device.h LUT_*): world_objects.py feature vectors of ChopFood / BlenderFood (int(not done()),
+        // chop_state, blend_state), Switch / Block (switch_active / int(walkable)), Agent (orientation one-hot)
+        for (int st = 0; st < 4; ++st) {
+            lut[LUT_NDONE0 + st] = st == 0 ? 1.0 : 0.0;
+            lut[LUT_CH0 + st] = (st & 1) ? 1.0 : 0.0;
+            lut[LUT_MA0 + st] = (st & 2) ? 1.0 : 0.0;
+            lut[LUT_CF0 + st] = st != 0 ? 1.0 : 0.0;
+        }
+        for (int k = 1; k <= 4; ++k) lut[LUT_OR0 + 8 * (k - 1) + k] = 1.0;
+        // ... followed by one word per lane for the observer-relative features (cz_kernels.h observe): lane 16 a + code of the
+        // subtrahend table holds observer a's x (mask in the low half), y (high half) or nothing.  Axis codes (soa.py):
+        // 1 x, 2 y, 4 + 2 j x unless j == a, 5 + 2 j y unless j == a (an agent's own position is absolute, cooking_env.py:366-368)
+        uint32_t submask[64];
+        for (int l = 0; l < 64; ++l) {
+            const int a = l >> 4, code = l & 15;
+            const bool selx = code == 1 || (code >= 4 && !(code & 1) && (code - 4) / 2 != a);
+            const bool sely = code == 2 || (code >= 5 && (code & 1) && (code - 5) / 2 != a);
+            submask[l] = (selx ? 0x7F8u : 0u) | (sely ? 0x7F8u << 16 : 0u);
+        }
+        CREATE_CHK(hipMalloc(&h->d_lut, sizeof lut + sizeof submask));
         CREATE_CHK(hipMemcpy(h->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+        CREATE_CHK(hipMemcpy((char *)h->d_lut + sizeof lut, submask, sizeof submask, hipMemcpyHostToDevice));
         P.lut = h->d_lut;
         P.inv_w = (65536u + (uint32_t)P.W - 1u) / (uint32_t)P.W;
         for (uint32_t c = 0; c < 1024; ++c)
@@ -351,7 +373,7 @@ extern "C" int cz_destroy(cz_handle h) {
         destroy_t f = (destroy_t)dlsym(h->rccl, "ncclCommDestroy");
         if (f) f(h->comm);
     }
-    void *ptrs[] = {h->d_lut, h->d_state, h->d_lay_init, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out, h->d_stats_part,
+    void *ptrs[] = {h->d_dump, h->d_lut, h->d_state, h->d_lay_init, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out, h->d_stats_part,
                     h->d_actions, h->d_obs, h->d_small, h->d_gather};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -596,6 +618,11 @@ static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr) {
     // exposed: one step of a moderate batch.  (CZ_WT=0/1 overrides, for experiments.)
     P.wt = (P.actions != nullptr && (size_t)P.N * P.A * P.F * 8 <= ((size_t)128 << 20)) ? 1 : 0;
     if (h->wt_override >= 0) P.wt = h->wt_override;
+    if (P.actions) {          // the one-step kernels store rewards and flags unconditionally
+        if (!P.rewards) P.rewards = (double *)h->d_dump;
+        if (!P.term) P.term = (uint8_t *)h->d_dump;
+        if (!P.trunc) P.trunc = (uint8_t *)h->d_dump;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->ktime) {
         while (h->kev.size() < h->kev_used + 2) {
@@ -925,6 +952,10 @@ extern "C" int cz_rollout(cz_handle h, int32_t T, uint64_t seed, uint32_t step0,
                           uint8_t *d_term, uint8_t *d_trunc) {
     if (ready(h)) return 1;
     if (T < 1) return fail(h, "cz_rollout: T must be >= 1");
+    // (the kernel addresses rewards / flags with 32-bit offsets from the array base)
+    if ((uint64_t)T * (uint64_t)h->P.N * (uint64_t)h->P.A * 8ull > 0xFFFFFFFFull)
+        return fail(h, "cz_rollout: T * num_envs * num_agents * 8 must stay below 4 GiB (T <= %llu here): split the rollout",
+                    (unsigned long long)(0xFFFFFFFFull / ((uint64_t)h->P.N * h->P.A * 8ull)));
     if (set_device(h)) return 1;
     Params P = h->P;
     P.actions = nullptr; P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc;

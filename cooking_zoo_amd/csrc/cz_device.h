@@ -45,7 +45,11 @@ enum : uint32_t { COND_NONE = 0, COND_CHOPPED, COND_MASHED, COND_NOT_CHOPPED, CO
 enum : uint32_t { W_T = 0, W_MARKS, W_LAYOUT, W_STATUS, W_EPISODE, W_RECIPES, W_POOL, W_MARKS_HI };   // word 7: wide tables only
 enum : uint32_t { ST_DONE = 1, ST_TERM = 2, ST_TRUNC = 4 };
 // observation descriptor (one u32 per feature): (image halfword index * 2) | (axis code * 4) << 16  -- soa.py
-constexpr int LUT_Y0 = 63, LUT_ZERO = 126, LUT_ONE = 127;   // + entries 128..255 = 0.0, the "absent" zone
+constexpr int LUT_Y0 = 63, LUT_ZERO = 126, LUT_ONE = 127;
+// truth tables of the flag features, indexed by raw state bits (cz_create fills them): not done / chopped / mashed by the
+// object's chopped | mashed << 1; the cell flag by ACTIVE | WALK << 1; orientation == k at LUT_OR0 + 8 (k - 1) + orientation.
+// Everything else up to 255 is 0.0: the "absent" zone (entry 255 minus an agent coordinate stays inside 224..255).
+constexpr int LUT_NDONE0 = 128, LUT_CH0 = 132, LUT_MA0 = 136, LUT_CF0 = 140, LUT_OR0 = 144;
 // per-env statistics: u32 words and doubles
 enum : uint32_t { SU_EPISODES = 0, SU_STEPS, SU_LENSUM, SU_TRUNC, SU_TERM, SU_COMPLETED0, SU_WORDS = 16 };
 enum : uint32_t { SF_CUR0 = 0, SF_SUM0 = 4, SF_WORDS = 8 };

@@ -58,8 +58,9 @@ constexpr int OBS_CHUNK = 2 * OBS_PAIRS;   // descriptor words held per lane
 // [126] 0.0 | [127] 1.0 | [128..255] 0.0)
 template <int CPL>
 struct Lds {
+    int32_t sub[MAX_AGENTS][16];         // per observer: what to subtract (x8) for each axis code (first: two of its rows are read
+                                         // with one ds_read2_b32, whose offsets reach 1 KB)
     uint16_t img[Img<CPL>::HALFWORDS];   // objects 6 hw each | cells 4 hw each | agents 8 hw each | the "absent" halfword
-    int32_t sub[MAX_AGENTS][16];         // per observer: what to subtract (x8) for each axis code
     uint64_t locs[WIDE_NODES * CPL];     // recipe evaluation scratch: matched-location bit sets per node (CPL words each)
 };
 
@@ -109,7 +110,20 @@ __device__ __forceinline__ void strec(bool dev, void *sbase, uint32_t voff, T v)
 template <int OPL, int CPL, int NA>
 __device__ __forceinline__ void load_env(const Params &P, Env<OPL, CPL, NA> &e, const Ctx &cx, const uint32_t *__restrict__ rec, bool dev = false) {
     const uint32_t lane = (uint32_t)cx.lane;
-    const uint32_t h = ldrec<uint32_t>(dev, rec, (lane & 7u) * 4u);                         // header words
+    // header words: wave-uniform.  Ordinary launches read them with one scalar load (nothing in this kernel writes a record
+    // before its loads are done, and the scalar cache is cold at kernel start like every other cache); an overlapped launch
+    // needs the device-scope flavour, which only vector loads have: eight lanes load, v_readlane spreads
+    uint32_t hw[HDR_WORDS];
+    if (!dev) {
+        typedef const __attribute__((address_space(4))) uint32_t *kconst_u32;
+        const kconst_u32 hp = (kconst_u32)rec;
+#pragma unroll
+        for (int i = 0; i < HDR_WORDS; ++i) hw[i] = hp[i];
+    } else {
+        const uint32_t h = ldg_dev<uint32_t>(rec, (lane & 7u) * 4u);
+#pragma unroll
+        for (int i = 0; i < HDR_WORDS; ++i) hw[i] = rdl(h, i);
+    }
     const uint32_t aw = ldrec<uint32_t>(dev, rec, (AGENT_WORD0 + (lane & 3u)) * 4u);        // agent words, lane a = agent a
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
@@ -124,11 +138,14 @@ __device__ __forceinline__ void load_env(const Params &P, Env<OPL, CPL, NA> &e, 
         e.d0[k] = (s < (uint32_t)cx.D) ? a : 0u;
         e.d1[k] = (s < (uint32_t)cx.D) ? b : 0u;
     }
-    e.t = rdl(h, W_T); e.marks = rdl(h, W_MARKS); e.layout = rdl(h, W_LAYOUT); e.status = rdl(h, W_STATUS);
-    e.episode = rdl(h, W_EPISODE); e.recipes = rdl(h, W_RECIPES); e.pool = rdl(h, W_POOL);
+    // every load of the record is issued before anything looks at a header word (whose first use waits for the scalar load:
+    // without the fence the scheduler puts that wait, a memory round trip, in front of the remaining vector loads)
+    __builtin_amdgcn_sched_barrier(0);
+    e.t = hw[W_T]; e.marks = hw[W_MARKS]; e.layout = hw[W_LAYOUT]; e.status = hw[W_STATUS];
+    e.episode = hw[W_EPISODE]; e.recipes = hw[W_RECIPES]; e.pool = hw[W_POOL];
     // (this test is also where the wave waits for its late scalar arguments -- before any LDS traffic is in flight, which
     // shares the wait counter with scalar loads: measured 0.1 us better than letting the first use wait further down)
-    e.marks_hi = P.wide ? rdl(h, W_MARKS_HI) : 0u;
+    e.marks_hi = P.wide ? hw[W_MARKS_HI] : 0u;
     e.agw = (lane < (uint32_t)NA) ? aw : 0u;
 }
 
@@ -175,9 +192,9 @@ __device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL, N
 // the recipe rows of this env, one word per lane: lane 9r + i = word i of the row of recipe r
 __device__ __forceinline__ uint32_t load_recipe_rows(const Params &P, uint32_t recipes, int lane) {
     const uint32_t l = min((uint32_t)lane, 9u * (uint32_t)P.R - 1u);          // lanes past the rows re-read the last word
-    const uint32_t r = (l * 57u) >> 9, i = l - 9u * r;                         // l / 9 for l < 64
+    const uint32_t r = __umul24(l, 57u) >> 9, i = l - __umul24(r, 9u);        // l / 9 for l < 64
     const uint32_t id = (recipes >> (8u * r)) & 0xFFu;
-    return ldg<uint32_t>(P.recipes, (id * (1u + MAX_NODES) + i) * 4u);
+    return ldg<uint32_t>(P.recipes, (__umul24(id, 1u + MAX_NODES) + i) * 4u);
 }
 
 // every recipe of the env from scratch (reset): sets e.marks (and e.marks_hi for wide tables)
@@ -198,16 +215,19 @@ __device__ __forceinline__ void all_marks(const Params &P, Env<OPL, CPL, NA> &e,
     e.marks = lo; e.marks_hi = hi;
 }
 
+// the per-lane constant of the subtrahend table (observe): word `lane` behind the 256 doubles of the quotient table
+__device__ __forceinline__ uint32_t load_submask(const Params &P, int lane) { return ldg<uint32_t>(P.lut, (uint32_t)(LUT_SIZE * 8 + lane * 4)); }
+
 // once per kernel and workgroup: the quotient table (thread `tid` of `nthreads`), followed by a workgroup barrier
 __device__ __forceinline__ void init_lut(const Params &P, double *lut, int tid, int nthreads) {
-    for (int i = tid; i < LUT_SIZE; i += nthreads) lut[i] = i < 128 ? ldg<double>(P.lut, (uint32_t)i * 8u) : 0.0;
+    for (int i = tid; i < LUT_SIZE; i += nthreads) lut[i] = ldg<double>(P.lut, (uint32_t)i * 8u);
 }
 
 // once per kernel and env: the constant part of the image (cell coordinates)
 template <int CPL>
 __device__ __forceinline__ void init_lds(const Params &P, const Ctx &cx, Lds<CPL> &s) {
     const int lane = cx.lane;
-    if (lane == 0) s.img[Img<CPL>::ZERO] = (uint16_t)(LUT_ABSENT * 8);
+    s.img[Img<CPL>::ZERO] = (uint16_t)(LUT_ABSENT * 8);           // (every lane, same value: cheaper than switching lanes off)
     uint32_t *img32 = reinterpret_cast<uint32_t *>(s.img);
     const uint32_t c01 = (uint32_t)((P.W - 1) * 8) | ((uint32_t)((LUT_Y0 + P.H - 1) * 8) << 16);
 #pragma unroll
@@ -241,22 +261,25 @@ __device__ __forceinline__ void load_desc(const Params &P, uint32_t layout, int 
 // keep plain stores (policy in cz_api.hip launch_step).
 template <int OPL, int CPL, int NA>
 __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, Lds<CPL> &s,
-                                        const double *lut, uint32_t (&dsc)[OBS_CHUNK], double *__restrict__ out /* [A][F] of this env */,
+                                        const double *lut, uint32_t (&dsc)[OBS_CHUNK], uint32_t submask, double *__restrict__ out /* [A][F] of this env */,
                                         bool objs_changed = true, bool cells_changed = true) {
     uint32_t *img32 = reinterpret_cast<uint32_t *>(s.img);
     const uint32_t dead = (uint32_t)(LUT_ABSENT * 8) * 0x10001u;
     const uint32_t c01 = (uint32_t)((P.W - 1) * 8) | ((uint32_t)((LUT_Y0 + P.H - 1) * 8) << 16);
-    const uint32_t f0 = (uint32_t)(LUT_ZERO * 8) * 0x10001u;        // two "0.0" flags
+    // Flags are not computed: the halfword of a flag is the entry of a small truth table, indexed by the raw state bits
+    // (LUT_NDONE0 / LUT_CH0 / LUT_MA0 by chopped | mashed << 1, LUT_CF0 by the cell's ACTIVE | WALK << 1 bits, LUT_OR0 + 8 k
+    // by the orientation), so an image word is one multiply-add of the extracted field.
+    constexpr uint32_t PICK_XY = 0x0C010C00u;                       // v_perm_b32: bytes x, 0, y, 0 of a word x | y << 8 | ...
     // ---- objects: 3 dwords per slot (in a fused rollout only when an object moved or changed state since the last encode)
     if (objs_changed)
 #pragma unroll
     for (int k = 0; k < OPL; ++k) {
         const uint32_t w = e.d0[k];
         const bool alive = (w & D_ALIVE) != 0u;
-        const uint32_t ch = (w >> 25) & 1u, ma = (w >> 26) & 1u;
-        uint32_t q0 = (((w & 0xFFu) << 3) | ((w & 0xFF00u) << 11)) + c01;
-        uint32_t q1 = f0 + (((ch | ma) ^ 1u) << 3) + (ch << 19);
-        uint32_t q2 = ((uint32_t)(LUT_ZERO * 8) + (ma << 3)) | ((uint32_t)(LUT_ONE * 8) << 16);
+        const uint32_t st = (w >> 25) & 3u;
+        uint32_t q0 = (__builtin_amdgcn_perm(0u, w, PICK_XY) << 3) + c01;
+        uint32_t q1 = __umul24(st, 0x80008u) + ((uint32_t)(LUT_NDONE0 * 8) | ((uint32_t)(LUT_CH0 * 8) << 16));
+        uint32_t q2 = (st << 3) + ((uint32_t)(LUT_MA0 * 8) | ((uint32_t)(LUT_ONE * 8) << 16));
         q0 = alive ? q0 : dead; q1 = alive ? q1 : dead; q2 = alive ? q2 : dead;
         const int slot = cx.lane + 64 * k;
         img32[(Img<CPL>::OBJ0 >> 1) + 3 * slot] = q0;
@@ -266,27 +289,27 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
     // ---- cells: the mutable flag (switch_active / block walkable) + the constant 1
     if (cells_changed)
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        const uint32_t fa = ((e.cell[k] >> 5) | (e.cell[k] >> 6)) & 1u;
-        img32[(Img<CPL>::CELL0 >> 1) + 2 * (cx.lane + 64 * k) + 1] = ((uint32_t)(LUT_ZERO * 8) + (fa << 3)) | ((uint32_t)(LUT_ONE * 8) << 16);
-    }
+    for (int k = 0; k < CPL; ++k)
+        img32[(Img<CPL>::CELL0 >> 1) + 2 * (cx.lane + 64 * k) + 1] =
+            ((e.cell[k] >> 2) & 0x18u) | ((uint32_t)(LUT_CF0 * 8) | ((uint32_t)(LUT_ONE * 8) << 16));
     // ---- agents: 4 dwords each (lane a builds agent a's), and the per-observer subtrahend table
     {
         const uint32_t A = e.agw;
-        const uint32_t t = 1u << ((A >> 16) & 0xFFu);
+        const uint32_t o8 = __umul24((A >> 16) & 7u, 0x80008u);
         if (cx.lane < NA) {
-            uint32_t *ag = img32 + (Img<CPL>::AG0 >> 1) + 4 * cx.lane;
-            ag[0] = (((A & 0xFFu) << 3) | ((A & 0xFF00u) << 11)) + c01;
-            ag[1] = f0 + (((t >> 1) & 1u) << 3) + (((t >> 2) & 1u) << 19);
-            ag[2] = f0 + (((t >> 3) & 1u) << 3) + (((t >> 4) & 1u) << 19);
-            ag[3] = (uint32_t)(LUT_ONE * 8);
+            uint4_t agv;
+            agv.x = (__builtin_amdgcn_perm(0u, A, PICK_XY) << 3) + c01;
+            agv.y = o8 + ((uint32_t)((LUT_OR0 + 0) * 8) | ((uint32_t)((LUT_OR0 + 8) * 8) << 16));
+            agv.z = o8 + ((uint32_t)((LUT_OR0 + 16) * 8) | ((uint32_t)((LUT_OR0 + 24) * 8) << 16));
+            agv.w = (uint32_t)(LUT_ONE * 8);
+            *reinterpret_cast<uint4_t *>(img32 + (Img<CPL>::AG0 >> 1) + 4 * cx.lane) = agv;
         }
-        // sub[a][code]: lane 16a + code.  axis codes: 1 -> x, 2 -> y, 4+2j -> x unless j == a, 5+2j -> y unless j == a
-        const uint32_t obs_a = (uint32_t)cx.lane >> 4, code = (uint32_t)cx.lane & 15u;
-        const uint32_t Ao = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(obs_a << 2), (int)A);     // the observer's word
-        const uint32_t mx = 0x552u & ~(1u << (4u + 2u * obs_a)), my = 0xAA4u & ~(1u << (5u + 2u * obs_a));
-        const int v = (int)((((mx >> code) & 1u) ? ((Ao & 0xFFu) << 3) : 0u) + (((my >> code) & 1u) ? ((Ao & 0xFF00u) >> 5) : 0u));
-        if (cx.lane < 16 * NA) (&s.sub[0][0])[cx.lane] = v;
+        // sub[a][code]: lane 16a + code.  axis codes: 1 -> x, 2 -> y, 4+2j -> x unless j == a, 5+2j -> y unless j == a.  Which
+        // coordinate a lane's entry takes is a constant of the lane: `submask` (0x7F8 in the low half: x, in the high half:
+        // y), made by the host next to the quotient table and loaded with the prologue's loads.
+        const uint32_t Ao = (uint32_t)__builtin_amdgcn_ds_bpermute((cx.lane >> 4) << 2, (int)A);     // the observer's word
+        const uint32_t q = ((__builtin_amdgcn_perm(0u, Ao, PICK_XY) << 3) & submask);               // x * 8 | y * 8 << 16, masked
+        (&s.sub[0][0])[cx.lane] = (int)((q & 0xFFFFu) + (q >> 16));         // (rows of observers >= NA: never read)
     }
     __builtin_amdgcn_wave_barrier();             // one wave owns this LDS region: DS ops of a wave execute in order
     // One buffer resource per observer whose range is exactly that observer's row (F * 8 bytes): the per-lane offset
@@ -519,8 +542,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     static_assert(64 * EPW >= LUT_SIZE, "one table entry per thread");
     // the quotient table is shared by the workgroup: its load joins the other loads of the prologue (no branch here:
     // a branch would split the kernel-argument fetch into several dependent round trips)
-    double lutv = ldg<double>(P.lut, min(threadIdx.x, 127u) * 8u);
-    lutv = threadIdx.x < 128u ? lutv : 0.0;
+    const double lutv = ldg<double>(P.lut, min(threadIdx.x, (unsigned)LUT_SIZE - 1u) * 8u);
     Lds<CPL> &lds = lds_all[wave];
     Ctx cx{P.W, P.H, P.D, P.W * P.H, lane};
     CZ_STAMP(0);
@@ -579,6 +601,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     uint32_t rowv = load_recipe_rows(P, e.recipes, lane);
     uint32_t dsc[OBS_CHUNK];
     if (P.obs) load_desc(P, e.layout, 0, lane, dsc);
+    const uint32_t submask = load_submask(P, lane);
     const int64_t env_global = P.env_id_base + env;
     bool cells_dirty = false, objs_dirty = false, header_dirty = FUSED;
     bool img_objs = true, img_cells = true;                 // which parts of the LDS image the next encode must rebuild
@@ -639,25 +662,30 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
             }
             ret = 0.0;
         }
-        // ---- outputs of this step
+        // ---- outputs of this step.  One wave-uniform base pointer per array and a 32-bit per-lane offset (cz_rollout checks
+        // that T * N * A * 8 fits): the `global_store v, v_off, s[base]` form, no 64-bit per-lane address arithmetic.  The
+        // one-step kernels store unconditionally - the host hands them a scratch row for an array the caller does not want.
         const size_t row = FUSED ? ((size_t)t * Pt.N + env) : (size_t)env;
-        if (lane < NA) {
+        {
+            const uint32_t oidx = (uint32_t)row * (uint32_t)NA + (uint32_t)lane;          // [row][agent]
             double *const rewards = kp->rewards;
             uint8_t *const term = kp->term, *const trunc = kp->trunc;
-            // (write-through in an overlapped run: the next launch rewrites the same bytes, possibly from another XCD)
-            if (rewards) strec<double>(chained, rewards + row * NA, (uint32_t)lane * 8u, myrew);
-            if (term) strec<uint8_t>(chained, term + row * NA, (uint32_t)lane, (uint8_t)o.term);
-            if (trunc) strec<uint8_t>(chained, trunc + row * NA, (uint32_t)lane, (uint8_t)o.trunc);
+            if (lane < NA) {
+                // (write-through in an overlapped run: the next launch rewrites the same bytes, possibly from another XCD)
+                if (!FUSED || rewards) strec<double>(chained, rewards, oidx * 8u, myrew);
+                if (!FUSED || term) strec<uint8_t>(chained, term, oidx, (uint8_t)o.term);
+                if (!FUSED || trunc) strec<uint8_t>(chained, trunc, oidx, (uint8_t)o.trunc);
+            }
         }
         if (!FUSED) {
             uint32_t *const marks_out = kp->marks_out;
-            if (marks_out && lane < 2) strec<uint32_t>(chained, marks_out + 2 * (size_t)env, (uint32_t)lane * 4u, lane == 0 ? e.marks : e.marks_hi);   // infos["recipe_done"] of the host API
+            if (marks_out && lane < 2) strec<uint32_t>(chained, marks_out, (2u * (uint32_t)env + (uint32_t)lane) * 4u, lane == 0 ? e.marks : e.marks_hi);   // infos["recipe_done"] of the host API
         }
         CZ_STAMP(5);
         img_objs |= (dt.touched | dt.moved) != 0;
         img_cells |= dt.cells != 0;
         if (Pt.obs) {
-            observe(Pt, e, cx, lds, lut, dsc, Pt.obs + row * (size_t)NA * Pt.F, img_objs, img_cells);
+            observe(Pt, e, cx, lds, lut, dsc, submask, Pt.obs + row * (size_t)NA * Pt.F, img_objs, img_cells);
             img_objs = false; img_cells = false;
         }
         CZ_STAMP(6);
@@ -728,7 +756,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin,
     if (obs_out) {
         uint32_t dsc[OBS_CHUNK];
         load_desc(P, e.layout, 0, lane, dsc);
-        observe(P, e, cx, lds, lut, dsc, obs_out + (size_t)i * NA * P.F);
+        observe(P, e, cx, lds, lut, dsc, load_submask(P, lane), obs_out + (size_t)i * NA * P.F);
     }
 }
 
@@ -746,7 +774,7 @@ __global__ __launch_bounds__(64) void k_observe(const Params P, int64_t env_begi
     load_env(P, e, cx, P.state + (size_t)(env_begin + i) * P.RW);
     uint32_t dsc[OBS_CHUNK];
     load_desc(P, e.layout, 0, lane, dsc);
-    observe(P, e, cx, lds, lut, dsc, obs_out + (size_t)i * NA * P.F);
+    observe(P, e, cx, lds, lut, dsc, load_submask(P, lane), obs_out + (size_t)i * NA * P.F);
 }
 
 // launchers exported by each instantiation unit

@@ -6,5 +6,6 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03
 python -m pytest tests -m gpu -x -q -k "$K" 2>&1 | tail -8 > gpurun_out/r03/tests_$TAG.log
 bash tools/interact_probe.sh > gpurun_out/r03/ip_$TAG.txt 2>&1
+python3 tools/mode_timing.py > gpurun_out/r03/modes_$TAG.txt 2>&1; (cd .ab/prev && python3 ../../tools/mode_timing.py) > gpurun_out/r03/modes_prev_$TAG.txt 2>&1
 if [ -d .ab/prev ]; then CZ_CHAIN=0 bash tools/ab_trees.sh .ab/prev . 2 > gpurun_out/r03/ab_$TAG.txt 2>&1; fi
-cat gpurun_out/r03/tests_$TAG.log gpurun_out/r03/ip_$TAG.txt gpurun_out/r03/ab_$TAG.txt
+cat gpurun_out/r03/modes_$TAG.txt gpurun_out/r03/modes_prev_$TAG.txt gpurun_out/r03/tests_$TAG.log gpurun_out/r03/ip_$TAG.txt gpurun_out/r03/ab_$TAG.txt
