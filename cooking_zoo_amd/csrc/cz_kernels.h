@@ -4,14 +4,15 @@
 
 namespace cz {
 
-// Diagnostic build only (make prof -> libcookingzoo_hip_prof.so, -DCZ_PROFILE): s_memtime stamps at phase boundaries,
+// Diagnostic build only (make prof -> libcookingzoo_hip_prof.so, -DCZ_PROFILE): s_memrealtime stamps (100 MHz, one clock for
+// the whole device, so that first start / last end of a launch can be read across XCDs) at phase boundaries,
 // written to a buffer of their own (Params::stamps); the shipped library contains none of this.
 #ifdef CZ_PROFILE
 #define CZ_STAMP(i)                                                                                    \
     do {                                                                                               \
         unsigned long long _t;                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                             \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                     \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                 \
         __builtin_amdgcn_sched_barrier(0);                                                             \
         if (lane == 0 && P.stamps) P.stamps[(size_t)env * 8 + (i)] = _t;                               \
     } while (0)

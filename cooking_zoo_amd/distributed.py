@@ -135,6 +135,11 @@ class FileRendezvous:
         env = os.environ if env is None else env
         rank, world = int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1"))
         path = env.get("CZ_RDZV_DIR")
+        if not path and world == 1 and "WORLD_SIZE" not in env:
+            # a lone process nobody launched: a directory of its own (two `python bench.py` runs of one shell share parent
+            # pid and start time, and a crashed earlier run may have left files behind under the derived name)
+            base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+            path = tempfile.mkdtemp(prefix=f"cz_rdzv_solo_{os.getpid()}_", dir=base)
         if not path:
             ppid = os.getppid()
             try:
@@ -232,6 +237,39 @@ def launch_local(n_ranks: int, argv: Sequence[str], *, extra_env: Optional[Dict[
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     rdzv = tempfile.mkdtemp(prefix="cz_rdzv_", dir=base)
     procs: List[subprocess.Popen] = []
+
+    def kill_live() -> None:
+        """every child that is still running: killed by its own process-group id (start_new_session: pgid == pid of exactly
+        this child), then reaped"""
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+
+    # The children live in sessions of their own, so a signal aimed at this process (Ctrl-C, `timeout N python bench.py
+    # --gpus 8`, a driver's kill) does not reach them by itself: it is turned into an exception here, and the `finally`
+    # below kills them before the rendezvous directory goes away.  (SIGKILL of this process cannot be caught: the children
+    # then notice the missing parent through the rendezvous timeout.)
+    class _Signalled(BaseException):
+        pass
+
+    def on_signal(signum, frame):
+        raise _Signalled(signum)
+
+    previous = {}
+    if threading.current_thread() is threading.main_thread():
+        for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            try:
+                previous[sig] = signal.signal(sig, on_signal)
+            except (ValueError, OSError):
+                pass
     try:
         for r in range(n_ranks):
             env = dict(os.environ)
@@ -255,15 +293,17 @@ def launch_local(n_ranks: int, argv: Sequence[str], *, extra_env: Optional[Dict[
                     rc = 124
                 break
             time.sleep(0.02)
-        for p in live:                                   # only on failure / timeout
-            try:
-                os.killpg(p.pid, signal.SIGKILL)         # start_new_session: pgid == pid of exactly this child
-            except ProcessLookupError:
-                pass
-            p.wait()
         return rc
+    except _Signalled as sig:
+        return 128 + int(sig.args[0])
     finally:
-        shutil.rmtree(rdzv, ignore_errors=True)
+        kill_live()                                      # a no-op when every rank has exited by itself
+        for sig, old in previous.items():
+            try:
+                signal.signal(sig, old)
+            except (ValueError, OSError):
+                pass
+        shutil.rmtree(rdzv, ignore_errors=True)          # only after the children are gone
 
 
 def comm_init_with_deadline(env, world_size: int, rank: int, rdzv: FileRendezvous, seconds: float = 120.0) -> Tuple[bool, str]:

@@ -117,3 +117,40 @@ def test_abandoned_hand_off_makes_every_rank_measure_again(who):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and "gave up waiting" in d["overlap_fallback"]
     assert "measuring again with launch-boundary ordering" in p.stderr
+
+
+def test_launcher_interrupted_kills_its_ranks(tmp_path):
+    """SIGTERM to the launching process (a driver's kill, `timeout N python bench.py --gpus 8`): the ranks, which live in
+    sessions of their own, are killed by the launcher before it leaves; nothing keeps running (and holding a GPU)."""
+    import signal
+    import time
+    pidfile = tmp_path / "pids"
+    child = textwrap.dedent(f"""
+        import os, time
+        open({str(pidfile)!r} + "." + os.environ["RANK"], "w").write(str(os.getpid()))
+        time.sleep(120)
+    """)
+    script = tmp_path / "child.py"
+    script.write_text(child)
+    launcher = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {REPO!r})
+        from cooking_zoo_amd.distributed import launch_local
+        sys.exit(launch_local(2, [{str(script)!r}], timeout=100.0))
+    """)
+    p = subprocess.Popen([sys.executable, "-c", launcher])
+    deadline = time.monotonic() + 60
+    while time.monotonic() < deadline and not all(os.path.exists(f"{pidfile}.{r}") and open(f"{pidfile}.{r}").read() for r in range(2)):
+        time.sleep(0.05)
+    pids = [int(open(f"{pidfile}.{r}").read()) for r in range(2)]
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    time.sleep(0.2)
+    for pid in pids:
+        gone = False
+        try:
+            os.kill(pid, 0)
+            gone = open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[0] == "Z"     # a zombie nobody reaps is gone too
+        except (ProcessLookupError, FileNotFoundError):
+            gone = True
+        assert gone, f"rank process {pid} survived its launcher"

@@ -27,10 +27,12 @@ d_rew = env.alloc((N, 2), np.float64)
 d_t = env.alloc((N, 2), np.uint8)
 d_u = env.alloc((N, 2), np.uint8)
 names = ["prologue+loads", "agents", "progress", "rewards/flags", "outputs", "observe", "store"]
+MODE = sys.argv[2] if len(sys.argv) > 2 else "random"
+TICK_NS = 10.0                      # s_memrealtime: 100 MHz
 acc = []
 spread, endspread, evt_us = [], [], []
 for it in range(60):
-    d_act.from_host(rng.integers(0, 5, size=(N, 2), dtype=np.int32))
+    d_act.from_host(rng.integers(0, 5, size=(N, 2), dtype=np.int32) if MODE == "random" else np.zeros((N, 2), np.int32))
     L.cz_timer_start(h)
     env.step_device(d_act, d_obs, d_rew, d_t, d_u)
     ms = C.c_float()
@@ -45,10 +47,10 @@ for it in range(60):
 d = np.concatenate(acc)
 tot = np.median((np.concatenate([a.sum(axis=1) for a in acc])))
 life = np.concatenate([a.sum(axis=1) for a in acc])
-print(f"wave lifetime cycles: median {tot:.0f}  p90 {np.percentile(life,90):.0f}  p99 {np.percentile(life,99):.0f}  max-per-launch median {np.median([a.sum(axis=1).max() for a in acc]):.0f}")
+print(f"[{MODE}] wave lifetime in 10 ns ticks: median {tot:.0f}  p90 {np.percentile(life,90):.0f}  p99 {np.percentile(life,99):.0f}  max-per-launch median {np.median([a.sum(axis=1).max() for a in acc]):.0f}")
 st = np.concatenate([ (a[:,0]*0) for a in acc])
 print(f"event-timed launch (diagnostic build, incl. stamp stores): median {np.median(evt_us):.2f} us")
-print("per-launch: first-start -> last-start", np.median(spread), "cycles; first-start -> last-end", np.median(endspread), "cycles")
+print("per-launch: first-start -> last-start", np.median(spread) * TICK_NS, "ns; first-start -> last-end", np.median(endspread) * TICK_NS, "ns")
 for i, n in enumerate(names):
     print(f"  {n:16s} median {np.median(d[:, i]):8.0f}  mean {d[:, i].mean():8.0f}  ({100 * d[:, i].mean() / d.sum(axis=1).mean():4.1f} %)")
 
