@@ -45,6 +45,7 @@ SYMBOLS = [
     ("cz_sizeof_config", _I32, []),
     ("cz_sizeof_stats", _I32, []),
     ("cz_debug_set_stamps", C.c_int, [_VP, _VP]),
+    ("cz_debug_set_timeline", C.c_int, [_VP, _VP, _I32]),
     ("cz_sync", C.c_int, [_VP]),
     ("cz_load_recipes", C.c_int, [_VP, _VP, _I32, _I32]),
     ("cz_load_layouts", C.c_int, [_VP, _VP, _VP, _I32]),

@@ -179,6 +179,9 @@ struct cz_handle_s {
     int n_ranks = 1, rank = 0;
     int wt_override = -1;          // CZ_WT experiment switch, read once
     bool huge = false;             // the 256-slot / 1024-cell instance (its own LDS image layout)
+    unsigned long long *tl_base = nullptr;   // timeline build: stamp buffer, its capacity in launches, launches so far
+    int32_t tl_cap = 0;
+    int64_t tl_count = 0;
     bool graphs_enabled = true;    // CZ_GRAPHS=0: cz_step_device_ring launches everything directly
     int32_t ring_prefix = 0;       // CZ_RING_PREFIX: steps of a cz_step_device_ring call launched directly in front of its first graph
     size_t zero_copy_bytes = (size_t)256 << 10;   // cz_step: batches whose buffers fit use the pinned device-mapped block (CZ_ZERO_COPY_BYTES)
@@ -216,6 +219,20 @@ extern "C" int cz_debug_set_stamps(cz_handle h, void *d_buf) {
     return fail(h, "cz_debug_set_stamps: this is not the diagnostic build (make prof)");
 #endif
     return 0;
+}
+// timeline builds only (tools/timeline.py): launch k of the step kernel writes its waves' entry / exit stamps to
+// d_buf + (k % cap_launches) * num_envs * 2 (uint64); cap_launches = 0 switches it off
+extern "C" int cz_debug_set_timeline(cz_handle h, void *d_buf, int32_t cap_launches) {
+    if (!h) return 1;
+#ifdef CZ_TIMELINE
+    h->tl_base = (unsigned long long *)d_buf;
+    h->tl_cap = d_buf ? cap_launches : 0;
+    h->tl_count = 0;
+    return 0;
+#else
+    (void)d_buf; (void)cap_launches;
+    return fail(h, "cz_debug_set_timeline: this is not the timeline build (make timeline)");
+#endif
 }
 extern "C" int32_t cz_sizeof_config(void) { return (int32_t)sizeof(cz_config); }
 extern "C" int32_t cz_sizeof_stats(void) { return (int32_t)sizeof(cz_stats); }
@@ -281,8 +298,13 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     h->chain_wanted_by_env = getenv("CZ_CHAIN") && atoi(getenv("CZ_CHAIN")) != 0;
     if (const char *s = getenv("CZ_RING_PREFIX")) h->ring_prefix = atoi(s) < 0 ? 0 : (atoi(s) > 16 ? 16 : atoi(s));
     if (const char *s = getenv("CZ_ZERO_COPY_BYTES")) h->zero_copy_bytes = (size_t)atoll(s);
-    if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // honoured by the diagnostic build only
+    if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // honoured by the ablation build only
+#ifdef CZ_SMALL_ONLY       // diagnostic libraries that carry the small instance only
+    if (!(P.D <= 64 && C <= 64)) { fail(nullptr, "cz_create: this diagnostic library holds the small kernel instance only"); cz_destroy(h); return 1; }
+    h->kl = launchers_small();
+#else
     h->kl = (P.D <= 64 && C <= 64) ? launchers_small() : (P.D <= 128 && C <= 256) ? launchers_large() : launchers_huge();
+#endif
     h->huge = P.D > 128 || C > 256;
     {   // Overlapped launches: a kernel's waves spin until their predecessors, waves of the previous kernel, have run.  A
         // wave that waits for a workgroup which cannot be dispatched because waiting waves hold the slots it needs would
@@ -623,6 +645,9 @@ static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr) {
         if (!P.term) P.term = (uint8_t *)h->d_dump;
         if (!P.trunc) P.trunc = (uint8_t *)h->d_dump;
     }
+#ifdef CZ_TIMELINE
+    P.timeline = (h->tl_base && h->tl_cap > 0) ? h->tl_base + (size_t)(h->tl_count++ % h->tl_cap) * (size_t)P.N * 2 : nullptr;
+#endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->ktime) {
         while (h->kev.size() < h->kev_used + 2) {

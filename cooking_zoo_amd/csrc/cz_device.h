@@ -87,8 +87,13 @@ struct Params {
     uint32_t *chain_err;           // pinned host word: an overlapped launch whose hand-off never came sets it (cz_sync fails on it)
 #endif
     uint32_t seq;                  // per-env hand-off of overlapped launches (SEQ_*); travels as a leading scalar argument
+#ifdef CZ_TIMELINE
+    unsigned long long *timeline;  // timeline build only (make timeline): [N][2] entry / exit stamps of this launch's waves, or nullptr
+#endif
 };
+#ifndef CZ_TIMELINE
 static_assert(sizeof(Params) == 264, "argument block: see the note above");
+#endif
 // Overlapped ("chained") launches: consecutive step kernels of a run go to two streams alternately, so a kernel may start
 // while its predecessor still runs; what orders them is a sequence word per env (64 B apart, right behind the records):
 // a wave waits until its env's word equals the launch's number, steps, and publishes number + 1.  The launch boundary
@@ -98,6 +103,14 @@ static_assert(sizeof(Params) == 264, "argument block: see the note above");
 constexpr uint32_t SEQ_PUBLISH = 1u << 31, SEQ_WAIT = 1u << 30, SEQ_MASK = SEQ_WAIT - 1u;
 constexpr int SEQ_STRIDE_WORDS = 16;
 
+#ifndef CZ_PRIO
+#define CZ_PRIO 1
+#endif
+#if CZ_PRIO
+#define CZ_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define CZ_SETPRIO(p) do { } while (0)
+#endif
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rdl(uint32_t v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -503,7 +516,16 @@ struct Ops {
         return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
     }
 
+    // what the walking half hands to the interacting half (lane a = agent a; `inter`: the agents that interact)
+    struct Pre { uint64_t inter; uint32_t txy, c, act; };
+
     static __device__ __forceinline__ void perform_agent_actions(E &e, const Ctx &cx, uint32_t act_raw, Dirty &dt) {
+        const Pre pre = agents_walk(e, cx, act_raw, dt);
+        agents_interact(e, cx, pre, dt);
+    }
+
+    // pre-pass, both filters and all walking: after this the agents' positions and orientations are final for the step
+    static __device__ __forceinline__ Pre agents_walk(E &e, const Ctx &cx, uint32_t act_raw, Dirty &dt) {
         const uint32_t W = (uint32_t)cx.W, H = (uint32_t)cx.H;
         const uint32_t agw = e.agw;                                        // 0 on lanes >= NA
         const uint32_t x = agw & 0xFFu, y = (agw >> 8) & 0xFFu, xy = agw & 0xFFFFu;
@@ -577,7 +599,19 @@ struct Ops {
                 cell_update(e, cx, (int)rdl(c, a), 0, CELL_ACTIVE, dt);
             } while (press);
         }
-        uint64_t inter = agent_m & ~walks_m & (SCHEME == 3 ? moving_m : ballot(act >= 5u));
+        return Pre{agent_m & ~walks_m & (SCHEME == 3 ? moving_m : ballot(act >= 5u)), txy, c, act};
+    }
+
+    // the interacting agents, serially in index order
+    static __device__ __forceinline__ void agents_interact(E &e, const Ctx &cx, const Pre &pre, Dirty &dt) {
+        const uint32_t W = (uint32_t)cx.W, H = (uint32_t)cx.H;
+        const uint32_t txy = pre.txy, c = pre.c, act = pre.act;
+        uint64_t inter = pre.inter;
+        // A launch lasts as long as its slowest wave, and the slowest waves are the ones with the most to resolve: they
+        // take the issue slots first (s_setprio: 1 with one interacting agent, 2 with more, 3 while recipe graphs are
+        // evaluated in step_env), the quick majority fills in behind them.
+        if (inter & (inter - 1)) CZ_SETPRIO(2);
+        else if (inter) CZ_SETPRIO(1);
         while (inter) {
             const int a = __builtin_ctzll(inter);
             inter &= inter - 1;

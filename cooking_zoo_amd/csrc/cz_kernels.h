@@ -473,7 +473,11 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
                 const uint32_t mb_r = (before >> (8 * r)) & 0xFF;
                 const bool visible = ((relmask >> (9 * r + 1)) & 0xFFull) != 0ull;
                 const bool sensitive = dt.statechg != 0u || ((sensmask >> (9 * r + 1)) & 0xFFull) != 0ull;
-                const uint32_t ma = (visible && sensitive) ? O::recipe_marks(e, cx, rowv, 9 * r, lds.locs) : mb_r;
+                uint32_t ma = mb_r;
+                if (visible && sensitive) {
+                    CZ_SETPRIO(3);
+                    ma = O::recipe_marks(e, cx, rowv, 9 * r, lds.locs);
+                }
                 after |= ma << (8 * r);
                 if (ma != mb_r) {
                     // goals_completed sums (recipe.py:36-40): open goal slots before / after
@@ -529,6 +533,12 @@ template <int OPL, int CPL, int NA, int SCHEME, bool FUSED, bool CHAIN>
 __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
                                             int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
                                             int32_t e_dyn1, uint32_t e_seq, const Params &P0) {
+#ifdef CZ_TIMELINE
+    // Timeline build (make timeline -> libcookingzoo_hip_tl.so): the shipped kernel plus two reads of the device-wide 100 MHz
+    // clock per wave - at its first instruction and behind its last store (for an overlapped launch: behind the publish) - and
+    // one 16-byte store of lane 0.  No waits are added in between (unlike the phase stamps of `make prof`).
+    const uint64_t tl_in = wall_clock64();
+#endif
     Params P = P0;
     P.state = e_state; P.actions = e_actions; P.lut = e_lut; P.N = e_N; P.RW = e_RW; P.W = e_W; P.H = e_H; P.D = e_D;
     P.dyn0_off = e_dyn0; P.dyn1_off = e_dyn1;
@@ -701,6 +711,21 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         if (lane == 0) stg_wt<uint32_t>(seqw, 0, ((e_seq & SEQ_MASK) + 1u) & SEQ_MASK);
     }
     CZ_STAMP(7);
+#ifdef CZ_TIMELINE
+    {
+        // word 0: entry time (low 32 bits) | HW_ID << 32 (wave, SIMD, CU, SH, SE);  word 1: exit time | XCC_ID << 32
+        const uint64_t tl_out = wall_clock64();
+        const uint32_t hw_id = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+        unsigned long long *const tl = CZ_LATE_STEP()->timeline;
+        if (tl && lane == 0) {
+            typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+            ull2 v;
+            v.x = (tl_in & 0xFFFFFFFFull) | ((unsigned long long)hw_id << 32);
+            v.y = (tl_out & 0xFFFFFFFFull) | ((unsigned long long)xcc << 32);
+            *reinterpret_cast<ull2 *>(tl + 2 * (size_t)env) = v;
+        }
+    }
+#endif
 }
 
 template <int OPL, int CPL, int NA, int SCHEME, bool FUSED>

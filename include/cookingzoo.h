@@ -71,7 +71,11 @@ int32_t cz_record_words(cz_handle h);
 int32_t cz_abi_version(void);
 int32_t cz_sizeof_config(void);                           /* sizeof(cz_config), for binding self-checks */
 int32_t cz_sizeof_stats(void);
-int cz_debug_set_stamps(cz_handle h, void *d_buf);       /* diagnostic builds only (make prof): s_memtime stamp buffer */
+int cz_debug_set_stamps(cz_handle h, void *d_buf);       /* diagnostic builds only (make prof): phase stamp buffer */
+/* timeline builds only (make timeline, tools/timeline.py): every step-kernel launch k writes two uint64 per env - entry and
+ * exit time of the env's wave on the device-wide 100 MHz clock, with the hardware ids in the upper halves - to
+ * d_buf + (k % cap_launches) * num_envs * 2 */
+int cz_debug_set_timeline(cz_handle h, void *d_buf, int32_t cap_launches);
 int cz_sync(cz_handle h);                                  /* wait for the handle's stream */
 /* Order all further work of this handle on a HIP stream of the caller (hipStream_t; e.g. the stream a framework runs its
  * policy on: device-pointer steps then need no host synchronisation on either side).  NULL restores the handle's own

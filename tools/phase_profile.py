@@ -58,3 +58,9 @@ slow = d[life > np.percentile(life, 99)]
 print("slowest 1% of waves: mean cycles per phase")
 for i, n in enumerate(names):
     print(f"  {n:16s} {slow[:, i].mean():8.0f}")
+
+print("the slowest wave of each launch: mean ticks per phase")
+worst = np.stack([a[a.sum(axis=1).argmax()] for a in acc])
+for i, n in enumerate(names):
+    print(f"  {n:16s} {worst[:, i].mean():8.0f}")
+print("  total", worst.sum(axis=1).mean())
