@@ -333,18 +333,18 @@ def worker_body(args, rdzv, overlap, note):
     n_ev = max(R * K, 4000)
     _native.check(h, L.cz_ring_prepare(h, n_ev, *ring, 0, *outs))
     barrier()
-    L.cz_timer_start(h)
+    _native.check(h, L.cz_timer_start(h))
     run_steps(n_ev, 0)                                         # the ring end to end, as few replays as possible
-    L.cz_timer_stop(h, C.byref(ev_ms))                         # event after the last launch, synchronised
+    _native.check(h, L.cz_timer_stop(h, C.byref(ev_ms)))       # event after the last launch, synchronised (fails if a hand-off was abandoned)
     kernel_us = [ev_ms.value * 1e3 / n_ev]
     # the same launches ordered by launch boundaries only (overlap switched off for this pass): the duration of one kernel
     # when nothing runs beside it, which is what a per-kernel trace of such a run shows
     was = max(L.cz_set_overlap(h, 0), 0)
     _native.check(h, L.cz_ring_prepare(h, n_ev, *ring, 0, *outs))
     barrier()
-    L.cz_timer_start(h)
+    _native.check(h, L.cz_timer_start(h))
     run_steps(n_ev, 0)
-    L.cz_timer_stop(h, C.byref(ev_ms))
+    _native.check(h, L.cz_timer_stop(h, C.byref(ev_ms)))
     kernel_us.append(ev_ms.value * 1e3 / n_ev)
     L.cz_set_overlap(h, was)
     overlapped = bool(c_k.value)

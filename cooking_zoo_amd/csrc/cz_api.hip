@@ -101,6 +101,15 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_probe_fill(void *dst, uint
         __builtin_amdgcn_raw_buffer_store_b128(u4{0, 0, 0, 0}, rs, off, 0, 16);
 }
 
+// test aid (cz_probe_occupy): a foreign kernel that does nothing but hold its workgroups' slots - the step kernel's block
+// size and LDS footprint - for `ticks` of the 100 MHz device clock
+__global__ __launch_bounds__(64 * ENVS_PER_WG) void k_probe_occupy(unsigned long long ticks, int *sink) {
+    __shared__ char hold[34 * 1024];
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (sink) sink[0] = hold[threadIdx.x];          // never true: keeps the allocation alive
+}
+
 // cz_load_layouts with a smaller pool: how many resident records still point past the new pool (layout id or redraw slice)
 __global__ void k_layout_misfits(const uint32_t *__restrict__ state, int RW, int N, uint32_t n_new, unsigned long long *count) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,6 +137,7 @@ struct cz_handle_s {
     hipStream_t own_stream = nullptr;  // the one cz_create made (cz_set_stream may point `stream` at a caller's)
     // overlapped ("chained") runs of cz_step_device_ring: odd steps go to aux_stream (SEQ_* in cz_device.h)
     hipStream_t aux_stream = nullptr;
+    hipStream_t foreign_stream = nullptr;   // cz_probe_occupy only
     hipEvent_t ev_fork = nullptr;
     bool chain_enabled = false;        // cz_set_overlap / CZ_CHAIN=1; off: runs are ordered by launch boundaries only (graph replay)
     int64_t chain_max_envs = 0;        // largest batch that may overlap (half of the envs the device holds at once, see cz_create)
@@ -143,6 +153,7 @@ struct cz_handle_s {
     cz_stats *d_stats_out = nullptr;
     unsigned long long *d_stats_part = nullptr;   // [256 chains][16 columns] between the two stages of the reduction
     double *d_lut = nullptr;
+    int32_t *d_reset_words = nullptr;  // [3][N]: layout ids, recipe words, pool words of a cz_reset call
     void *d_dump = nullptr;            // [N][4] doubles: where a one-step launch writes an output array the caller passed as NULL
     // staging for the host-pointer API
     int32_t *d_actions = nullptr;
@@ -208,6 +219,26 @@ static int fail(cz_handle h, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *cz_last_error(cz_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+// An overlapped launch whose hand-off never came sets the pinned word h_chain_err and leaves; from then on the env states are
+// void and EVERY entry point that launches, synchronises or reads results fails (not only cz_sync), until the caller replaces
+// the whole state (cz_set_state / cz_reset over all envs), which is the documented recovery.
+static int chain_failed(cz_handle h, const char *where) {
+    if (!h->h_chain_err) return 0;
+    const uint32_t w = *(volatile uint32_t *)h->h_chain_err;
+    if (!w) return 0;
+    return fail(h, "%s: an overlapped launch gave up waiting for its predecessor (the envs' states are no longer trustworthy; "
+                   "replace them all with cz_set_state or cz_reset to go on): waited for number %u, last saw ...%u (mod 64), the "
+                   "handle's next number is %u", where, w & 0xFFFFFFu, (w >> 24) & 63u, h->seq_counter);
+}
+// all envs have been given a new state: whatever an abandoned run left behind is gone with the old one
+static int chain_recover(cz_handle h) {
+    if (!h->h_chain_err || !*(volatile uint32_t *)h->h_chain_err) return 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->aux_stream) HIPCHK(h, hipStreamSynchronize(h->aux_stream));      // every waiting wave has left by now (it saw the word)
+    *(volatile uint32_t *)h->h_chain_err = 0;
+    return 0;
+}
 extern "C" int32_t cz_abi_version(void) { return 3; }
 // diagnostic builds only (tools/phase_profile.py): where the kernels write their s_memtime stamps
 extern "C" int cz_debug_set_stamps(cz_handle h, void *d_buf) {
@@ -337,6 +368,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     CREATE_CHK(hipMemsetAsync(h->d_stat_f, 0, N * SF_WORDS * 8, h->stream));
     CREATE_CHK(hipMalloc(&h->d_stats_out, sizeof(cz_stats)));
     CREATE_CHK(hipMalloc(&h->d_dump, N * MAX_AGENTS * sizeof(double)));
+    CREATE_CHK(hipMalloc(&h->d_reset_words, N * 3 * sizeof(int32_t)));
     CREATE_CHK(hipMalloc(&h->d_stats_part, (size_t)STAT_CHAINS * 16 * sizeof(unsigned long long)));
     CREATE_CHK(hipStreamSynchronize(h->stream));
     P.state = h->d_state; P.stat_u = h->d_stat_u; P.stat_f = h->d_stat_f;
@@ -389,13 +421,14 @@ extern "C" int cz_destroy(cz_handle h) {
     (void)hipSetDevice(h->cfg.device_id);
     (void)hipStreamSynchronize(h->stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+    if (h->foreign_stream) { (void)hipStreamSynchronize(h->foreign_stream); (void)hipStreamDestroy(h->foreign_stream); }
     if (h->chain_enabled) (void)cz_set_overlap(h, 0);
     if (h->comm && h->rccl) {
         typedef int (*destroy_t)(void *);
         destroy_t f = (destroy_t)dlsym(h->rccl, "ncclCommDestroy");
         if (f) f(h->comm);
     }
-    void *ptrs[] = {h->d_dump, h->d_lut, h->d_state, h->d_lay_init, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out, h->d_stats_part,
+    void *ptrs[] = {h->d_reset_words, h->d_dump, h->d_lut, h->d_state, h->d_lay_init, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out, h->d_stats_part,
                     h->d_actions, h->d_obs, h->d_small, h->d_gather};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -431,7 +464,6 @@ extern "C" int cz_sync(cz_handle h) {
     if (!h) return fail(nullptr, "null handle");
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->h_chain_err && *(volatile uint32_t *)h->h_chain_err) {
-        const uint32_t w = *(volatile uint32_t *)h->h_chain_err;
         if (getenv("CZ_CHAIN_DEBUG")) {          // histogram of the sequence words at the time of the report
             (void)hipDeviceSynchronize();
             std::vector<uint32_t> sq((size_t)h->P.N * SEQ_STRIDE_WORDS);
@@ -447,9 +479,7 @@ extern "C" int cz_sync(cz_handle h) {
             }
             fprintf(stderr, "\n");
         }
-        return fail(h, "cz_sync: an overlapped launch gave up waiting for its predecessor (the envs' states are no longer trustworthy): "
-                       "waited for number %u, last saw ...%u (mod 64), the handle's next number is %u",
-                    w & 0xFFFFFFu, (w >> 24) & 63u, h->seq_counter);
+        return chain_failed(h, "cz_sync");
     }
     return 0;
 }
@@ -604,6 +634,8 @@ extern "C" int cz_set_state(cz_handle h, int64_t b, int64_t c, const uint32_t *r
         if (count && h->n_layouts > 0 && (int)(base + count) > h->n_layouts) return fail(h, "cz_set_state: record %lld: layout pool slice out of range", (long long)i);
     }
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (b == 0 && c == h->P.N) { if (chain_recover(h)) return 1; }
+    else if (chain_failed(h, "cz_set_state")) return 1;
     HIPCHK(h, hipMemcpyAsync(h->d_state + (size_t)b * h->P.RW, records, (size_t)c * h->P.RW * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -616,16 +648,8 @@ extern "C" int cz_get_state(cz_handle h, int64_t b, int64_t c, uint32_t *records
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipMemcpyAsync(records, h->d_state + (size_t)b * h->P.RW, (size_t)c * h->P.RW * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return 0;
+    return chain_failed(h, "cz_get_state");
 }
-
-// device scratch of one call: released on every return path
-struct Scratch {
-    void *p = nullptr;
-    ~Scratch() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
-    template <class T> T *as() const { return static_cast<T *>(p); }
-};
 
 static int ready(cz_handle h) {
     if (!h) return fail(nullptr, "null handle");
@@ -635,6 +659,7 @@ static int ready(cz_handle h) {
 }
 
 static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr) {
+    if (chain_failed(h, "step launch")) return 1;
     if (!stream) stream = h->stream;
     // write-through observation stores pay when the launch is short enough for the end-of-kernel L2 write-back to be
     // exposed: one step of a moderate batch.  (CZ_WT=0/1 overrides, for experiments.)
@@ -717,21 +742,22 @@ extern "C" int cz_reset(cz_handle h, int64_t b, int64_t c, const int32_t *layout
             pools[(size_t)i] = pool_words[i];
         }
     }
-    Scratch s_lay, s_rec, s_pool, s_obs;
-    HIPCHK(h, s_lay.alloc((size_t)c * 4));
-    HIPCHK(h, s_rec.alloc((size_t)c * 4));
-    HIPCHK(h, s_pool.alloc((size_t)c * 4));
-    HIPCHK(h, hipMemcpyAsync(s_lay.p, layout_ids, (size_t)c * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(s_rec.p, recipe_ids, (size_t)c * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(s_pool.p, pools.data(), (size_t)c * 4, hipMemcpyHostToDevice, h->stream));
+    if (b == 0 && c == h->P.N) { if (chain_recover(h)) return 1; }
+    else if (chain_failed(h, "cz_reset")) return 1;
+    // persistent scratch of the handle (cz_create: three words per env; the observation staging is shared with cz_step / cz_observe)
+    int32_t *const d_lay = h->d_reset_words;
+    uint32_t *const d_rec = (uint32_t *)h->d_reset_words + h->P.N, *const d_pool = (uint32_t *)h->d_reset_words + 2 * (size_t)h->P.N;
+    HIPCHK(h, hipMemcpyAsync(d_lay, layout_ids, (size_t)c * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_rec, recipe_ids, (size_t)c * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_pool, pools.data(), (size_t)c * 4, hipMemcpyHostToDevice, h->stream));
     size_t ob = (size_t)c * h->P.A * h->P.F * 8;
-    if (obs) HIPCHK(h, s_obs.alloc(ob));
+    if (obs && !h->d_obs) HIPCHK(h, hipMalloc(&h->d_obs, (size_t)h->P.N * h->P.A * h->P.F * 8));
     Params P = h->P;
     hipLaunchKernelGGL(k_count_aborted, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, h->stream, h->d_stat_u, h->d_state, h->P.RW,
                        (long long)b, (int)c);
-    hipError_t rc = h->kl.reset(P, h->stream, b, (int)c, s_lay.as<int32_t>(), s_rec.as<uint32_t>(), s_pool.as<uint32_t>(), s_obs.as<double>());
-    if (rc == hipSuccess && obs) rc = hipMemcpyAsync(obs, s_obs.p, ob, hipMemcpyDeviceToHost, h->stream);
-    const hipError_t rs = hipStreamSynchronize(h->stream);            // the scratch must outlive the kernel in any case
+    hipError_t rc = h->kl.reset(P, h->stream, b, (int)c, d_lay, d_rec, d_pool, obs ? h->d_obs : nullptr);
+    if (rc == hipSuccess && obs) rc = hipMemcpyAsync(obs, h->d_obs, ob, hipMemcpyDeviceToHost, h->stream);
+    const hipError_t rs = hipStreamSynchronize(h->stream);            // (pools, a host vector, must outlive its copy)
     HIPCHK(h, rc);
     HIPCHK(h, rs);
     return 0;
@@ -743,12 +769,12 @@ extern "C" int cz_observe(cz_handle h, int64_t b, int64_t c, double *obs) {
     if (c == 0) return 0;
     if (!obs) return fail(h, "cz_observe: null buffer");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    Scratch s_obs;
+    if (chain_failed(h, "cz_observe")) return 1;
     size_t ob = (size_t)c * h->P.A * h->P.F * 8;
-    HIPCHK(h, s_obs.alloc(ob));
+    if (!h->d_obs) HIPCHK(h, hipMalloc(&h->d_obs, (size_t)h->P.N * h->P.A * h->P.F * 8));
     Params P = h->P;
-    hipError_t rc = h->kl.observe(P, h->stream, b, (int)c, s_obs.as<double>());
-    if (rc == hipSuccess) rc = hipMemcpyAsync(obs, s_obs.p, ob, hipMemcpyDeviceToHost, h->stream);
+    hipError_t rc = h->kl.observe(P, h->stream, b, (int)c, h->d_obs);
+    if (rc == hipSuccess) rc = hipMemcpyAsync(obs, h->d_obs, ob, hipMemcpyDeviceToHost, h->stream);
     const hipError_t rs = hipStreamSynchronize(h->stream);
     HIPCHK(h, rc);
     HIPCHK(h, rs);
@@ -1111,6 +1137,20 @@ extern "C" int cz_probe_output_only(cz_handle h, void *d_dst, size_t bytes, int3
     return 0;
 }
 
+// Test aid: `workgroups` workgroups of a foreign kernel (512 threads, 34 KB of LDS each, like the step kernel's) that hold
+// their slots for `microseconds`, launched on a stream of its own that nothing else of this handle is ordered on; returns at
+// once.  What a caller's own long-running kernels do to a device that an overlapped run (cz_set_overlap) counts on having for
+// itself: tests/test_gpu_large.py runs one under such a run and checks the documented outcome.
+extern "C" int cz_probe_occupy(cz_handle h, int32_t workgroups, int32_t microseconds) {
+    if (!h || workgroups < 1 || microseconds < 0) return fail(h, "cz_probe_occupy: bad arguments");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (!h->foreign_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->foreign_stream, hipStreamNonBlocking));
+    hipLaunchKernelGGL(k_probe_occupy, dim3((unsigned)workgroups), dim3(64 * ENVS_PER_WG), 0, h->foreign_stream,
+                       (unsigned long long)microseconds * 100ull, (int *)nullptr);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 // ---- device memory + timing helpers --------------------------------------------------------------------
 extern "C" void *cz_dev_alloc(cz_handle h, size_t bytes) {
     if (!h) return nullptr;
@@ -1154,7 +1194,7 @@ extern "C" int cz_memcpy_d2h(cz_handle h, void *d, const void *s, size_t n) {
     if (!h) return fail(nullptr, "null handle");
     HIPCHK(h, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return 0;
+    return chain_failed(h, "cz_memcpy_d2h");
 }
 extern "C" int cz_timer_start(cz_handle h) {
     if (!h) return fail(nullptr, "null handle");
@@ -1166,7 +1206,7 @@ extern "C" int cz_timer_stop(cz_handle h, float *ms) {
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev1));
     HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
-    return 0;
+    return chain_failed(h, "cz_timer_stop");
 }
 extern "C" int cz_kernel_time_reset(cz_handle h, int32_t enable) {
     if (!h) return fail(nullptr, "null handle");
@@ -1206,7 +1246,7 @@ extern "C" int cz_get_stats(cz_handle h, cz_stats *out) {
     if (stats_reduce(h)) return 1;
     HIPCHK(h, hipMemcpyAsync(out, h->d_stats_out, sizeof(cz_stats), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return 0;
+    return chain_failed(h, "cz_get_stats");
 }
 extern "C" int cz_reset_stats(cz_handle h) {
     if (!h) return fail(nullptr, "null handle");
@@ -1292,7 +1332,7 @@ extern "C" int cz_stats_allgather(cz_handle h, cz_stats *out) {
     if (r) return fail(h, "ncclAllGather failed: %d", r);
     HIPCHK(h, hipMemcpyAsync(out, h->d_gather, sizeof(cz_stats) * (size_t)h->n_ranks, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return 0;
+    return chain_failed(h, "cz_stats_allgather");
 }
 
 // Barrier over the communicator: a 4-byte RCCL all-reduce on the handle's stream, then a stream synchronisation.  Every

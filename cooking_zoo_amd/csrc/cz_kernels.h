@@ -603,6 +603,11 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
             }
         }
     }
+    // (Ordering of the hand-off: the poll's load has returned - its value was read by the branch above - before any load
+    // below is issued; those are device-scope loads (sc1), served from behind the XCDs' L2s like the predecessor's
+    // write-through stores, which were acknowledged before it published.  So no acquire fence is needed by the hardware - an
+    // agent-scope one would invalidate the L2 on every poll - but the compiler must not move the loads up:)
+    if (CHAIN) asm volatile("" ::: "memory");
     // ---- every load of the step is issued here, before anything waits
     if (!FUSED && !CHAIN) av = ldg<int>(P.actions + (size_t)env * NA, (uint32_t)min(lane, NA - 1) * 4u);
     double ret = ldrec<double>(chained, retp, ((uint32_t)lane & 3u) * 8u);                                       // running episode return, lane a = agent a
@@ -734,6 +739,11 @@ __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_st
                                                           int32_t e_dyn1, const Params P0) {
     step_kernel<OPL, CPL, NA, SCHEME, FUSED, false>(e_state, e_actions, e_lut, e_N, e_RW, e_W, e_H, e_D, e_dyn0, e_dyn1, 0u, P0);
 }
+// Overlapped launches exist for the small instance only (one slot and one cell per lane: every shipped level): that is where
+// the gain was measured (4096 envs of the 7x7 levels), and the only instance that meets the eight-waves target below
+// without spilling vector registers - the 2 / 4 instance spilled 9-37 VGPRs to scratch under it, the 4 / 16 instance cannot
+// meet it at all.  Batches of the larger instances are bound by their observation writes and replay graphs.
+template <int OPL, int CPL> constexpr bool chain_instance() { return OPL == 1 && CPL == 1; }
 // (one more leading scalar: the launch's sequence word; it fills the padding in front of P0, whose offset stays the same)
 // Eight waves per SIMD (<= 96 SGPRs, at the price of ~45 spilled ones): four workgroups per CU, so that two of these
 // kernels are resident IN FULL at the batch sizes that may overlap.  With the 106 SGPRs the compiler takes by itself only
@@ -818,10 +828,12 @@ struct Inst {
     static hipError_t resident_na(const Params &P, int num_cus, int64_t *envs) {
         constexpr int EPW = envs_per_wg<CPL>();
         int per_cu = 0;
-        hipError_t e;
-        if (P.scheme == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step_chain<OPL, CPL, NA, 3>, 64 * EPW, 0);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step_chain<OPL, CPL, NA, 1>, 64 * EPW, 0);
-        *envs = (int64_t)per_cu * num_cus * EPW;
+        hipError_t e = hipSuccess;
+        if constexpr (chain_instance<OPL, CPL>()) {
+            if (P.scheme == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step_chain<OPL, CPL, NA, 3>, 64 * EPW, 0);
+            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step_chain<OPL, CPL, NA, 1>, 64 * EPW, 0);
+        }
+        *envs = (int64_t)per_cu * num_cus * EPW;          // 0: this instance never overlaps
         return e;
     }
     static hipError_t resident_envs(const Params &P, int num_cus, int64_t *envs) {
@@ -842,8 +854,12 @@ struct Inst {
 #define CZ_LAUNCH_CHAIN(S) \
     hipLaunchKernelGGL((k_step_chain<OPL, CPL, NA, S>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, E.seq, P)
         if (P.actions && (P.seq & SEQ_PUBLISH)) {
-            if (P.scheme == 3) CZ_LAUNCH_CHAIN(3);
-            else CZ_LAUNCH_CHAIN(1);
+            if constexpr (chain_instance<OPL, CPL>()) {
+                if (P.scheme == 3) CZ_LAUNCH_CHAIN(3);
+                else CZ_LAUNCH_CHAIN(1);
+            } else {
+                return hipErrorInvalidValue;               // (cz_overlap_limit is 0 for this instance: the host never asks)
+            }
         } else if (P.actions) {
             if (P.scheme == 3) CZ_LAUNCH_STEP(3, false);
             else CZ_LAUNCH_STEP(1, false);

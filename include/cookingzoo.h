@@ -169,7 +169,15 @@ int cz_launch_counts(cz_handle h, int64_t *graph_kernels, int64_t *direct_kernel
  *     stores are write-through (up to 128 MiB of observations per step), and never inside a stream capture of the caller.  Everything else is replayed from graphs as before.
  *   - One handle per device and process may have it switched on (cz_set_overlap returns -1 for a second one): the
  *     waiting kernels of two handles together could fill the device.  CZ_CHAIN=1 switches it on at cz_create.
- *   - A hand-off that does not arrive within two seconds marks the handle (cz_sync then fails) instead of hanging.
+ *   - A hand-off that does not arrive within two seconds marks the handle instead of hanging: from then on EVERY call that
+ *     launches, synchronises or reads results fails (cz_sync, cz_step_device*, cz_rollout, cz_get_state, cz_get_stats,
+ *     cz_stats_allgather, cz_memcpy_d2h, cz_timer_stop, ...), because the env states are void.  Recovery: give every env a
+ *     new state - cz_set_state or cz_reset over the whole range [0, num_envs) - which clears the mark.
+ *   - This is an OPEN-LOOP mode: the launches of a run need their actions before the run starts, and every launch of a
+ *     run overwrites the same output buffers (only the last step's outputs can be read).  A closed loop (observation ->
+ *     policy -> action) uses cz_step_device; open-loop work that wants every step's outputs uses cz_rollout.
+ *   - Only the small kernel instance (at most 64 object slots and 64 cells: every shipped level) overlaps; for the larger
+ *     instances cz_overlap_limit is 0.
  * cz_set_overlap returns the previous setting (0 / 1) or -1; cz_chain_counts reports how many kernels went out
  * overlapped (reset != 0: zero after reading). */
 int cz_set_overlap(cz_handle h, int32_t enabled);
@@ -206,6 +214,10 @@ int cz_kernel_time_read(cz_handle h, double *total_ms, int64_t *launches);
  * nothing but write `bytes` (<= 2 GiB) to d_dst with the encode's 16-byte write-through stores -- the floor of a launch
  * that has to emit that much output (bench.py reports it next to the roofline).  d_dst is overwritten. */
 int cz_probe_output_only(cz_handle h, void *d_dst, size_t bytes, int32_t reps, float *us_per_launch);
+/* test aid: `workgroups` workgroups of a foreign kernel (512 threads and 34 KB of LDS each, like the step kernel's) hold
+ * their slots for `microseconds` on a stream of their own; returns at once.  Stands in for a caller's own long-running
+ * kernels next to an overlapped run. */
+int cz_probe_occupy(cz_handle h, int32_t workgroups, int32_t microseconds);
 
 /* ---- statistics + multi-GPU ------------------------------------------------------------------------- */
 int cz_get_stats(cz_handle h, cz_stats *out);              /* device reduction over this handle's envs */
