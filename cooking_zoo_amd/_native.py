@@ -49,6 +49,9 @@ SYMBOLS = [
     ("cz_sync", C.c_int, [_VP]),
     ("cz_load_recipes", C.c_int, [_VP, _VP, _I32, _I32]),
     ("cz_load_layouts", C.c_int, [_VP, _VP, _VP, _I32]),
+    ("cz_update_layouts", C.c_int, [_VP, _I32, _I32, _VP, _VP]),
+    ("cz_set_layout_group", C.c_int, [_VP, _I32, _I32]),
+    ("cz_layout_updates", _I64, [_VP]),
     ("cz_set_state", C.c_int, [_VP, _I64, _I64, _VP]),
     ("cz_get_state", C.c_int, [_VP, _I64, _I64, _VP]),
     ("cz_reset", C.c_int, [_VP, _I64, _I64, _VP, _VP, _VP, _VP]),
@@ -69,6 +72,7 @@ SYMBOLS = [
     ("cz_rollout", C.c_int, [_VP, _I32, _U64, _U32, _VP, _VP, _VP, _VP]),
     ("cz_action", _U32, [_U64, _I64, _I32, _U32, _U32]),
     ("cz_next_layout", _U32, [_I64, _U32, _U32, _U32]),
+    ("cz_next_layout_group", _U32, [_I64, _U32, _U32, _U32, _U32, _U32]),
     ("cz_dev_alloc", _VP, [_VP, C.c_size_t]),
     ("cz_dev_free", C.c_int, [_VP, _VP]),
     ("cz_host_alloc", _VP, [_VP, C.c_size_t]),

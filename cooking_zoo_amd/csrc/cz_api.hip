@@ -148,6 +148,17 @@ struct cz_handle_s {
     Launchers kl;
     int n_layouts = 0, n_recipes = 0;
     uint32_t *d_state = nullptr, *d_lay_init = nullptr, *d_lay_desc = nullptr, *d_recipes = nullptr;
+    uint32_t *d_lay_block = nullptr;       // the allocation behind d_lay_init: LAY_CTL_WORDS control words, then the records
+    char *h_lay_stage = nullptr;           // pinned staging of cz_update_layouts: [L] records, then [L] descriptors
+    hipStream_t copy_stream = nullptr;     // cz_update_layouts copies run here, beside the steps
+    hipEvent_t ev_copy_done = nullptr, ev_steps_issued = nullptr;
+    bool copy_pending = false;             // a copy has been issued that no cz_set_layout_group has waited for yet
+    struct SlotRange { int32_t first, count; };
+    std::vector<SlotRange> upd_ranges;     // staged by cz_update_layouts, not copied yet (flush_updates)
+    std::vector<SlotRange> staged_on_copy, staged_on_main;   // the slots of the latest copy issued on the copy stream / in order on the handle's stream
+    hipEvent_t ev_main_copy_done = nullptr;
+    int32_t lay_groups = 1, lay_active = 0;
+    int64_t n_layout_updates = 0;
     uint32_t *d_stat_u = nullptr;
     double *d_stat_f = nullptr;
     cz_stats *d_stats_out = nullptr;
@@ -201,6 +212,9 @@ struct cz_handle_s {
 };
 
 static thread_local std::string g_err;
+static int ready(cz_handle h);
+static int set_device(cz_handle h);
+static int flush_updates(cz_handle h, bool force);
 
 static int fail(cz_handle h, const char *fmt, ...) {
     char buf[512];
@@ -239,7 +253,7 @@ static int chain_recover(cz_handle h) {
     *(volatile uint32_t *)h->h_chain_err = 0;
     return 0;
 }
-extern "C" int32_t cz_abi_version(void) { return 3; }
+extern "C" int32_t cz_abi_version(void) { return 4; }
 // diagnostic builds only (tools/phase_profile.py): where the kernels write their s_memtime stamps
 extern "C" int cz_debug_set_stamps(cz_handle h, void *d_buf) {
     if (!h) return 1;
@@ -272,6 +286,10 @@ extern "C" uint32_t cz_action(uint64_t seed, int64_t env_global, int32_t agent, 
 }
 extern "C" uint32_t cz_next_layout(int64_t env_global, uint32_t episode, uint32_t pool_word, uint32_t n_layouts) {
     return next_layout(env_global, episode, pool_word, n_layouts);
+}
+extern "C" uint32_t cz_next_layout_group(int64_t env_global, uint32_t episode, uint32_t pool_word, uint32_t n_layouts, uint32_t groups,
+                                         uint32_t active) {
+    return next_layout(env_global, episode, pool_word, n_layouts, groups ? groups : 1u, active);
 }
 
 extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
@@ -428,12 +446,17 @@ extern "C" int cz_destroy(cz_handle h) {
         destroy_t f = (destroy_t)dlsym(h->rccl, "ncclCommDestroy");
         if (f) f(h->comm);
     }
-    void *ptrs[] = {h->d_reset_words, h->d_dump, h->d_lut, h->d_state, h->d_lay_init, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out, h->d_stats_part,
+    void *ptrs[] = {h->d_reset_words, h->d_dump, h->d_lut, h->d_state, h->d_lay_block, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out, h->d_stats_part,
                     h->d_actions, h->d_obs, h->d_small, h->d_gather};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &r : h->ring_graphs)
         if (r.ge) (void)hipGraphExecDestroy(r.ge);
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    if (h->ev_copy_done) (void)hipEventDestroy(h->ev_copy_done);
+    if (h->ev_steps_issued) (void)hipEventDestroy(h->ev_steps_issued);
+    if (h->ev_main_copy_done) (void)hipEventDestroy(h->ev_main_copy_done);
+    if (h->h_lay_stage) (void)hipHostFree(h->h_lay_stage);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->h_marks) (void)hipHostFree(h->h_marks);
@@ -566,9 +589,9 @@ extern "C" int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n, in
     return 0;
 }
 
-extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const uint32_t *obs_desc, int32_t n) {
-    if (!h || !init_records || !obs_desc || n < 1 || n > 65535) return fail(h, "cz_load_layouts: bad arguments");
-    // validate descriptors: halfword indices must address a slot / cell / agent of this batch, axis codes must exist
+// what the kernels rely on in a layout's tables: descriptors whose halfword indices address a slot / cell / agent of this batch
+// and whose axis codes exist; records in which a slot that is not alive carries no container tag (Ops::content_of)
+static int validate_layouts(cz_handle h, const char *who, const uint32_t *init_records, const uint32_t *obs_desc, int32_t n) {
     for (size_t i = 0; i < (size_t)n * h->P.F; ++i) {
         uint32_t off = obs_desc[i] & 0xFFFFu, code4 = obs_desc[i] >> 16;
         uint32_t hw = off >> 1, code = code4 >> 2;
@@ -579,10 +602,23 @@ extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const 
         else if (hw < ag0) ok = ok && (int)((hw - cell0) / 4) < h->P.W * h->P.H;
         else if (hw < zero) ok = ok && (int)((hw - ag0) / 8) < h->P.A && ((hw - ag0) & 7u) < 7u;
         else ok = ok && hw == zero;
-        if (!ok) return fail(h, "cz_load_layouts: bad observation descriptor %#x at %zu", obs_desc[i], i);
+        if (!ok) return fail(h, "%s: bad observation descriptor %#x at %zu", who, obs_desc[i], i);
     }
+    for (int32_t l = 0; l < n; ++l) {
+        const uint32_t *r = init_records + (size_t)l * h->P.RW;
+        for (int s2 = 0; s2 < h->P.D; ++s2)
+            if (!(r[h->P.dyn0_off + s2] & D_ALIVE) && (r[h->P.dyn1_off + s2] & 0xFFu))
+                return fail(h, "%s: layout %d: slot %d is not alive but carries a container tag", who, l, s2);
+    }
+    return 0;
+}
+
+extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const uint32_t *obs_desc, int32_t n) {
+    if (!h || !init_records || !obs_desc || n < 1 || n > 65535) return fail(h, "cz_load_layouts: bad arguments");
+    if (validate_layouts(h, "cz_load_layouts", init_records, obs_desc, n)) return 1;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->copy_stream) HIPCHK(h, hipStreamSynchronize(h->copy_stream));
     if (h->n_layouts > 0 && n < h->n_layouts) {
         // a smaller pool: the kernels index lay_desc / lay_init with the layout id and the redraw slice of every resident
         // record, so records that point past the new pool would read out of bounds on the next step / observe / auto-reset
@@ -598,20 +634,121 @@ extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const 
                            "cz_reset / cz_set_state them into the new range first, or load a pool that is not smaller",
                         misfits, n, h->n_layouts);
     }
-    if (h->d_lay_init) { HIPCHK(h, hipFree(h->d_lay_init)); h->d_lay_init = nullptr; h->P.lay_init = nullptr; }
+    if (h->d_lay_block) { HIPCHK(h, hipFree(h->d_lay_block)); h->d_lay_block = nullptr; h->d_lay_init = nullptr; h->P.lay_init = nullptr; }
     if (h->d_lay_desc) { HIPCHK(h, hipFree(h->d_lay_desc)); h->d_lay_desc = nullptr; h->P.lay_desc = nullptr; }
+    if (h->h_lay_stage) { HIPCHK(h, hipHostFree(h->h_lay_stage)); h->h_lay_stage = nullptr; }
     size_t b0 = (size_t)n * h->P.RW * 4, b1 = (size_t)n * h->P.F * 4;
-    HIPCHK(h, hipMalloc(&h->d_lay_init, b0));
+    // the records, behind LAY_CTL_WORDS control words (which part of their pool slices the envs draw from: all of it)
+    HIPCHK(h, hipMalloc(&h->d_lay_block, LAY_CTL_WORDS * 4 + b0));
+    h->d_lay_init = h->d_lay_block + LAY_CTL_WORDS;
     HIPCHK(h, hipMalloc(&h->d_lay_desc, b1 + 16));                 // + padding: descriptors are fetched in pairs
+    HIPCHK(h, hipMemsetAsync(h->d_lay_block, 0, LAY_CTL_WORDS * 4, h->stream));
+    HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->d_lay_block + LC_GROUPS), 1, 1, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_lay_desc, 0, b1 + 16, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_lay_init, init_records, b0, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_lay_desc, obs_desc, b1, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->n_layouts = n;
+    h->lay_groups = 1; h->lay_active = 0; h->upd_ranges.clear(); h->staged_on_copy.clear(); h->staged_on_main.clear(); h->copy_pending = false;
     h->tables_version++;
     h->P.lay_init = h->d_lay_init; h->P.lay_desc = h->d_lay_desc; h->P.L = n;
     return 0;
 }
+
+// the staged slot ranges of cz_update_layouts that still wait for their copy.  force = false: copy them (on the copy stream)
+// if the steps that were issued before the update have completed, else leave them for a later call; force = true: they have
+// to be in place before what the caller issues next - if those steps are still running, copy in order on the handle's stream.
+static int flush_updates(cz_handle h, bool force) {
+    if (h->upd_ranges.empty()) return 0;
+    const hipError_t q = hipEventQuery(h->ev_steps_issued);
+    if (q != hipSuccess) (void)hipGetLastError();
+    if (q != hipSuccess && !force) return 0;
+    const hipStream_t st = q == hipSuccess ? h->copy_stream : h->stream;
+    const size_t RWb = (size_t)h->P.RW * 4, Fb = (size_t)h->P.F * 4, L = (size_t)h->n_layouts;
+    for (const auto &r : h->upd_ranges) {
+        HIPCHK(h, hipMemcpyAsync(h->d_lay_init + (size_t)r.first * h->P.RW, h->h_lay_stage + (size_t)r.first * RWb, (size_t)r.count * RWb,
+                                 hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(h->d_lay_desc + (size_t)r.first * h->P.F, h->h_lay_stage + L * RWb + (size_t)r.first * Fb, (size_t)r.count * Fb,
+                                 hipMemcpyHostToDevice, st));
+    }
+    // (who reads which part of the staging block until when: cz_update_layouts waits before it rewrites the same slots)
+    if (st == h->copy_stream) {
+        HIPCHK(h, hipEventRecord(h->ev_copy_done, h->copy_stream));
+        h->copy_pending = true;
+        h->staged_on_copy = h->upd_ranges;
+    } else {
+        HIPCHK(h, hipEventRecord(h->ev_main_copy_done, h->stream));
+        h->staged_on_main = h->upd_ranges;
+    }
+    h->upd_ranges.clear();
+    return 0;
+}
+
+// Fresh layouts UNDER A STEPPING BATCH (the reference instantiates a new level at every reset, cooking_env.py:191-195 /
+// parsing.py:21-151; the device redraws from a resident pool): replaces pool slots [first, first + count) without touching
+// the handle's stream.  The tables stay where they are (nothing the launches captured changes), the new content goes
+// through a pinned staging block of the library (the caller's arrays are free again when this returns) and is copied by a
+// stream of its own, AFTER every step issued so far has completed (their envs may still read the old content) and not
+// waited for by later steps.  The caller must not replace slots that envs can still draw or are still playing on - that is what
+// cz_set_layout_group is for: cut every env's pool slice into groups, let the envs draw from one, refresh another once the
+// episodes that started on it are over (at most max_steps + 1 steps after the switch), then switch.  The switch waits for
+// the copies (on the device, not on the host), so an env only ever draws a slot whose update has completed.
+extern "C" int cz_update_layouts(cz_handle h, int32_t first, int32_t count, const uint32_t *init_records, const uint32_t *obs_desc) {
+    if (ready(h)) return 1;
+    if (first < 0 || count < 0 || first + count > h->n_layouts || (count > 0 && (!init_records || !obs_desc)))
+        return fail(h, "cz_update_layouts: slots [%d, %d) outside the resident pool of %d layouts", first, first + count, h ? h->n_layouts : 0);
+    if (count > 0 && validate_layouts(h, "cz_update_layouts", init_records, obs_desc, count)) return 1;
+    if (set_device(h)) return 1;
+    const size_t RWb = (size_t)h->P.RW * 4, Fb = (size_t)h->P.F * 4, L = (size_t)h->n_layouts;
+    if (!h->copy_stream) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_copy_done, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_steps_issued, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_main_copy_done, hipEventDisableTiming));
+    }
+    if (!h->h_lay_stage) HIPCHK(h, hipHostMalloc((void **)&h->h_lay_stage, L * (RWb + Fb), hipHostMallocDefault));
+    if (count == 0) return 0;               // (count 0: only sets up the copy stream and the staging block, ahead of time)
+    // The staging block has a place per slot.  Only an earlier copy of THESE slots that is still running, or not even issued,
+    // is in the way (with the rotation of cz_set_layout_group consecutive updates go to different parts of the pool).
+    auto overlaps = [&](const std::vector<cz_handle_s::SlotRange> &v) {
+        for (const auto &r : v)
+            if (r.first < first + count && first < r.first + r.count) return true;
+        return false;
+    };
+    if (overlaps(h->upd_ranges) && flush_updates(h, true)) return 1;
+    if (overlaps(h->staged_on_copy)) { HIPCHK(h, hipEventSynchronize(h->ev_copy_done)); h->staged_on_copy.clear(); }
+    if (overlaps(h->staged_on_main)) { HIPCHK(h, hipEventSynchronize(h->ev_main_copy_done)); h->staged_on_main.clear(); }
+    char *const st_rec = h->h_lay_stage + (size_t)first * RWb, *const st_desc = h->h_lay_stage + L * RWb + (size_t)first * Fb;
+    memcpy(st_rec, init_records, (size_t)count * RWb);
+    memcpy(st_desc, obs_desc, (size_t)count * Fb);
+    // The copy must come after every step issued so far (their envs may still read the old content).  A device-side wait of the
+    // copy stream for the handle's stream would do - and slow every step kernel down by a microsecond for as long as it is
+    // pending (a second hardware queue with an outstanding barrier: measured, tools/rot_probe.py).  So the copy is issued
+    // LATER, by whichever call of this handle first finds that those steps have completed (flush_updates), with nothing to
+    // wait for on the device.
+    HIPCHK(h, hipEventRecord(h->ev_steps_issued, h->stream));
+    h->upd_ranges.push_back({first, count});
+    h->n_layout_updates += count;
+    return flush_updates(h, false);
+}
+
+// From the next step on (stream order) every env draws its next episode's layout from part `active` of its pool slice cut
+// into `groups` equal parts (1, 0: the whole slice, the default).  Every slice's length must be a multiple of `groups`.
+// Waits - on the device - for the cz_update_layouts copies issued so far.
+extern "C" int cz_set_layout_group(cz_handle h, int32_t groups, int32_t active) {
+    if (ready(h)) return 1;
+    if (groups < 1 || groups > h->n_layouts || active < 0 || active >= groups || h->n_layouts % groups)
+        return fail(h, "cz_set_layout_group: need 1 <= groups, 0 <= active < groups, and pool slices that are multiples of groups");
+    if (set_device(h)) return 1;
+    if (flush_updates(h, true)) return 1;
+    if (h->copy_pending) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copy_done, 0)); h->copy_pending = false; }
+    HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->d_lay_block + LC_GROUPS), groups, 1, h->stream));
+    HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->d_lay_block + LC_ACTIVE), active, 1, h->stream));
+    h->lay_groups = groups; h->lay_active = active;
+    return 0;
+}
+// how many pool slots cz_update_layouts has replaced on this handle so far
+extern "C" int64_t cz_layout_updates(cz_handle h) { return h ? h->n_layout_updates : 0; }
 
 static int check_range(cz_handle h, int64_t b, int64_t c) {
     if (!h) return fail(nullptr, "null handle");
@@ -794,6 +931,7 @@ extern "C" int cz_step_device(cz_handle h, const int32_t *d_actions, double *d_o
     if (ready(h)) return 1;
     if (!d_actions) return fail(h, "cz_step_device: actions pointer is null");
     if (set_device(h)) return 1;
+    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
     Params P = h->P;
     P.actions = d_actions; P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
     P.marks_out = h->marks_out_next; h->marks_out_next = nullptr;
@@ -808,6 +946,7 @@ extern "C" int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_acti
     if (ready(h)) return 1;
     if (!d_actions || K < 1 || action_period < 1) return fail(h, "cz_step_device_many: bad arguments");
     if (set_device(h)) return 1;
+    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
     Params P = h->P;
     P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
     P.actions = d_actions;
@@ -935,6 +1074,7 @@ extern "C" int cz_step_device_ring(cz_handle h, int32_t K, const int32_t *d_ring
     if (ready(h)) return 1;
     if (!d_ring || K < 1 || period < 1 || first_slot < 0 || first_slot >= period) return fail(h, "cz_step_device_ring: bad arguments");
     if (set_device(h)) return 1;
+    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
     return ring_walk(h, K, d_ring, stride, period, first_slot, d_obs, d_rewards, d_term, d_trunc, true);
 }
 // the largest batch (envs of this handle's kernel) that two overlapped launches fit the device with; larger batches never overlap
@@ -1008,6 +1148,7 @@ extern "C" int cz_rollout(cz_handle h, int32_t T, uint64_t seed, uint32_t step0,
         return fail(h, "cz_rollout: T * num_envs * num_agents * 8 must stay below 4 GiB (T <= %llu here): split the rollout",
                     (unsigned long long)(0xFFFFFFFFull / ((uint64_t)h->P.N * h->P.A * 8ull)));
     if (set_device(h)) return 1;
+    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
     Params P = h->P;
     P.actions = nullptr; P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc;
     P.T = T; P.seed = seed; P.step0 = step0;

@@ -133,11 +133,19 @@ __host__ __device__ inline uint32_t action_hash(uint64_t seed, int64_t env_globa
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     return (uint32_t)(((uint64_t)x * (uint64_t)n) >> 32);
 }
-__host__ __device__ inline uint32_t next_layout(int64_t env_global, uint32_t episode, uint32_t pool_word, uint32_t n_layouts) {
+// The layout an env draws for its episode: keyed by the GLOBAL env id (sharding does not change it), inside the env's slice
+// of the pool (pool_word = base | count << 16, 0 = whole pool).  `groups` > 1 (cz_set_layout_group): the slice is cut into
+// that many equal parts and only part `active` is drawn from - the others can be refreshed meanwhile (cz_update_layouts).
+__host__ __device__ inline uint32_t next_layout(int64_t env_global, uint32_t episode, uint32_t pool_word, uint32_t n_layouts,
+                                                uint32_t groups = 1u, uint32_t active = 0u) {
     uint32_t base = pool_word & 0xFFFFu, count = pool_word >> 16;
     if (count == 0) { base = 0; count = n_layouts; }
+    if (groups > 1u) { count /= groups; base += active * count; }
     return base + (uint32_t)(((uint64_t)env_global + (uint64_t)episode * 7919u) % count);
 }
+// control words in front of the layout records (lay_init - LAY_CTL_WORDS): which part of their slices the envs draw from
+constexpr int LAY_CTL_WORDS = 16;
+enum : uint32_t { LC_GROUPS = 0, LC_ACTIVE = 1 };
 
 // wave-uniform bit set over N*64 positions (object slots or grid cells)
 template <int N>

@@ -383,9 +383,13 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
         if (P.auto_reset) {
             // next-step autoreset: reset() of cooking_env.py:178-210 from the layout pool
             e.episode += 1;
-            uint32_t lay = next_layout(env_global, e.episode, e.pool, (uint32_t)P.L);
+            const uint32_t *const lay0 = late_params(kp_off)->lay_init;
+            // (the control words are constant while a kernel runs: the host changes them between launches, in stream order)
+            typedef const __attribute__((address_space(4))) uint32_t *kconst_u32;
+            const kconst_u32 ctl = (kconst_u32)(lay0 - LAY_CTL_WORDS);
+            uint32_t lay = next_layout(env_global, e.episode, e.pool, (uint32_t)P.L, ctl[LC_GROUPS], ctl[LC_ACTIVE]);
             uint32_t recipes = e.recipes, episode = e.episode, pool = e.pool;
-            load_env(P, e, cx, late_params(kp_off)->lay_init + (size_t)lay * P.RW);
+            load_env(P, e, cx, lay0 + (size_t)lay * P.RW);
             e.t = 0; e.layout = lay; e.status = 0; e.episode = episode; e.recipes = recipes; e.pool = pool;
             all_marks(P, e, cx, rowv, lds);
             if (P.obs) load_desc(P, lay, 0, cx.lane, dsc);

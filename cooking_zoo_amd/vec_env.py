@@ -8,6 +8,7 @@ include/cookingzoo.h; this class only prepares tables (layout pool, recipe table
 from __future__ import annotations
 
 import ctypes as C
+import queue as _queue
 import random as _random
 
 import numpy as np
@@ -23,6 +24,32 @@ DEFAULT_REWARD_SCHEME = {"recipe_reward": 20, "max_time_penalty": -5, "recipe_pe
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _produce_layouts(q, stop, level_objects, meta, num_agents, dims_tuple, pool_slices, groups, seed):
+    """Body of the layout-rotation process (CookingVecEnv.rotate_layouts): batch b refills part b % groups of every level's
+    pool slice; its layouts come from random.Random streams keyed by (seed, b, level), so a run can be replayed."""
+    dims = soa.Dims(*dims_tuple)
+    b = 0
+    while not stop.is_set():
+        g = b % groups
+        batch = []
+        for li, lv in enumerate(level_objects):
+            base, count = pool_slices[li]
+            sub = count // groups
+            rng = _random.Random((int(seed) * 1000003 + b) * 101 + li)
+            lays = [_ll.instantiate(lv, meta, num_agents, rng) for _ in range(sub)]
+            first = base + g * sub
+            recs = np.stack([l.init_record(dims, first + k) for k, l in enumerate(lays)])
+            desc = np.stack([l.obs_descriptor(meta, dims) for l in lays])
+            batch.append((first, lays, recs, desc))
+        while not stop.is_set():
+            try:
+                q.put(batch, timeout=0.1)
+                break
+            except _queue.Full:
+                pass
+        b += 1
 
 
 class DeviceBuffer:
@@ -162,6 +189,10 @@ class CookingVecEnv:
         self._upload_layouts()
         self._buffers = []
         self.env_level = np.arange(self.num_envs) % len(self.levels)
+        self._steps = 0                       # env steps issued so far (every stepping method counts)
+        self._lay_groups, self._lay_active = 1, 0
+        self._rot = None                      # rotate_layouts state
+        self.rotation_events = []             # (step index, "group", groups, active) / (step index, "layouts", first slot, [Layout])
         if self._spawn_cfg[0] or self._spawn_cfg[1]:
             from cooking_zoo_amd.spawn import SpawnBook
             if len(self.levels) != 1:
@@ -186,6 +217,116 @@ class CookingVecEnv:
         self.pool_slices = [(0, len(self.layouts))]
         self._upload_layouts()
 
+    # ------------------------------------------------------------------ fresh layouts under a stepping batch
+    def update_layouts(self, first, layouts):
+        """Replace pool slots [first, first + len(layouts)) while the batch keeps stepping (cz_update_layouts: a copy stream
+        of the library's own; the handle's stream is not touched).  Only slots that no env can draw or is playing on."""
+        recs = np.stack([l.init_record(self.dims, first + k) for k, l in enumerate(layouts)])
+        desc = np.stack([l.obs_descriptor(self.meta, self.dims) for l in layouts])
+        self._update_layout_arrays(first, layouts, recs, desc)
+
+    def _update_layout_arrays(self, first, layouts, recs, desc):
+        _native.check(self._h, _native.lib().cz_update_layouts(self._h, int(first), len(layouts), _ptr(recs), _ptr(desc)))
+        self.layouts[first:first + len(layouts)] = list(layouts)
+        self._lay_records[first:first + len(layouts)] = recs
+        self._lay_desc[first:first + len(layouts)] = desc
+        self.rotation_events.append((self._steps, "layouts", int(first), list(layouts)))
+
+    def set_layout_group(self, groups, active):
+        """From the next step on the envs draw their next episodes from part `active` of their pool slices cut into `groups`
+        equal parts (cz_set_layout_group; waits on the device for the updates issued so far)."""
+        if any(count % groups for _, count in self.pool_slices):
+            raise ValueError("every level's pool slice must be a multiple of `groups` layouts long")
+        _native.check(self._h, _native.lib().cz_set_layout_group(self._h, int(groups), int(active)))
+        self._lay_groups, self._lay_active = int(groups), int(active)
+        self.rotation_events.append((self._steps, "group", int(groups), int(active)))
+
+    def rotate_layouts(self, every, *, groups=2, seed=0, prefetch=2):
+        """Keep the layout pool fresh while the batch steps - the batched counterpart of the reference instantiating a new
+        level at every reset (cooking_env.py:191-195, parsing.py:21-151).  The pool slices are cut into `groups` parts; the
+        envs draw from one; every `every` steps (at the next call boundary) the next part becomes the one drawn from, and
+        once the episodes that started on the old part are over (max_steps + 2 steps later) it is refilled with layouts
+        a background process has instantiated meanwhile (engine/load_level.py, its own seeded stream per refill).  Which
+        layouts an env sees is a function of the sequence of stepping calls only (the refill waits for that process if it
+        has to), so a run can be replayed: `rotation_events` lists what was switched / replaced at which step."""
+        if self._rot is not None:
+            raise RuntimeError("rotate_layouts is already running")
+        if groups < 2 or any(count % groups for _, count in self.pool_slices):
+            raise ValueError("need groups >= 2 and pool slices that are multiples of `groups` long")
+        if every < self.max_steps + 3:
+            raise ValueError("`every` must be at least max_steps + 3 steps: a part is refilled max_steps + 2 steps after the "
+                             "envs stopped drawing from it, and before they draw from it again")
+        rot = {"groups": int(groups), "every": int(every), "flip_due": self._steps + int(every), "refill_due": None, "n_refills": 0}
+
+        # The instantiation is plain Python (engine/load_level.py, the reference's draw order) and takes milliseconds per batch:
+        # in a thread it would hold the interpreter lock against the thread that issues the steps, so it runs in a process of
+        # its own (spawned: a fresh interpreter that never loads the HIP library) and hands finished arrays over a queue.
+        import multiprocessing as _mp
+        ctx = _mp.get_context("spawn")
+        rot["queue"] = ctx.Queue(maxsize=max(1, int(prefetch)))
+        rot["stop"] = ctx.Event()
+        rot["process"] = ctx.Process(target=_produce_layouts, name="cz-layout-rotation", daemon=True,
+                                     args=(rot["queue"], rot["stop"], self.level_objects, self.meta, self.num_agents, self.dims.as_tuple(),
+                                           list(self.pool_slices), int(groups), int(seed)))
+        # ... and a small thread takes the batches off the process queue (unpickling costs a millisecond) into a local one
+        rot["ready"] = _queue.Queue(maxsize=max(1, int(prefetch)))        # (bounded: when it is full everything upstream sleeps)
+
+        def drain():
+            batch = None
+            while not rot["stop"].is_set():
+                try:
+                    if batch is None:
+                        batch = rot["queue"].get(timeout=0.1)
+                    rot["ready"].put(batch, timeout=0.1)
+                    batch = None
+                except (_queue.Empty, _queue.Full):
+                    pass
+                except (EOFError, OSError):
+                    return
+        import threading as _threading
+        rot["drain"] = _threading.Thread(target=drain, name="cz-layout-rotation-drain", daemon=True)
+        self._rot = rot
+        _native.check(self._h, _native.lib().cz_update_layouts(self._h, 0, 0, None, None))     # copy stream + staging, ahead of time
+        self.set_layout_group(groups, self._lay_active if self._lay_groups == groups else 0)
+        rot["process"].start()
+        rot["drain"].start()
+
+    def stop_rotation(self):
+        if self._rot is not None:
+            rot, self._rot = self._rot, None
+            rot["stop"].set()
+            try:
+                while True:                                   # (a producer blocked on a full queue sees the stop flag within 0.1 s)
+                    rot["queue"].get_nowait()
+            except _queue.Empty:
+                pass
+            rot["drain"].join(timeout=5)
+            rot["process"].join(timeout=10)
+            if rot["process"].is_alive():
+                rot["process"].terminate()
+
+    def rotation_ready(self):
+        """refills the background process has ready right now (a measurement may want to start with a full queue)"""
+        return 0 if self._rot is None else self._rot["ready"].qsize()
+
+    def _advance(self, k):
+        """k more env steps have been issued: switch / refill when due"""
+        self._steps += int(k)
+        rot = self._rot
+        if rot is None:
+            return
+        if rot["refill_due"] is not None and self._steps >= rot["refill_due"]:
+            for first, lays, recs, desc in rot["ready"].get():              # (waits for the producer if it is behind)
+                self._update_layout_arrays(first, lays, recs, desc)
+            rot["refill_due"] = None
+            rot["n_refills"] += 1
+        if rot["refill_due"] is None and self._steps >= rot["flip_due"]:
+            old = self._lay_active
+            self.set_layout_group(rot["groups"], (old + 1) % rot["groups"])
+            assert old == rot["n_refills"] % rot["groups"]                    # the part the producer's next batch is made for
+            rot["refill_due"] = self._steps + self.max_steps + 2
+            rot["flip_due"] = self._steps + rot["every"]
+
     # ------------------------------------------------------------------ reset / step
     def initial_layout_ids(self):
         """Episode-0 layout of every env: the same keyed draw auto-reset uses (shard invariant)."""
@@ -195,7 +336,7 @@ class CookingVecEnv:
         for e in range(self.num_envs):
             base, count = self.pool_slices[self.env_level[e]]
             pools[e] = base | (count << 16)
-            ids[e] = L.cz_next_layout(self.env_id_base + e, 0, int(pools[e]), len(self.layouts))
+            ids[e] = L.cz_next_layout_group(self.env_id_base + e, 0, int(pools[e]), len(self.layouts), self._lay_groups, self._lay_active)
         return ids, pools
 
     def reset(self, layout_ids=None, return_obs=True, env_begin=0, env_count=None):
@@ -250,6 +391,7 @@ class CookingVecEnv:
         _native.check(self._h, _native.lib().cz_step(self._h, _ptr(acts), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc)))
         if self.spawn is not None:
             self._spawn_after_step(obs, trunc)
+        self._advance(1)
         return obs, rew, term, trunc
 
     def _spawn_after_step(self, obs, trunc):
@@ -328,11 +470,21 @@ class CookingVecEnv:
         p = _dev_ptr
         _native.check(self._h, _native.lib().cz_step_device(self._h, p(d_actions), p(d_obs), p(d_rewards), p(d_term),
                                                             p(d_trunc)))
+        self._advance(1)
+
+    def step_device_ring(self, K, d_ring, action_stride, action_period, first_slot, d_obs, d_rewards, d_term, d_trunc):
+        """K consecutive device-resident steps in one call (cz_step_device_ring: graph replay or overlapped launches); step k
+        reads its actions from ring slot (first_slot + k) % action_period."""
+        p = _dev_ptr
+        _native.check(self._h, _native.lib().cz_step_device_ring(self._h, int(K), p(d_ring), int(action_stride), int(action_period),
+                                                                 int(first_slot), p(d_obs), p(d_rewards), p(d_term), p(d_trunc)))
+        self._advance(K)
 
     def rollout(self, T, seed, step0=0, d_obs=None, d_rewards=None, d_term=None, d_trunc=None):
         p = _dev_ptr
         _native.check(self._h, _native.lib().cz_rollout(self._h, int(T), int(seed), int(step0), p(d_obs), p(d_rewards),
                                                         p(d_term), p(d_trunc)))
+        self._advance(T)
 
     def sync(self):
         _native.check(self._h, _native.lib().cz_sync(self._h))
@@ -357,6 +509,8 @@ class CookingVecEnv:
         _native.check(self._h, _native.lib().cz_reset_stats(self._h))
 
     def close(self):
+        if getattr(self, "_rot", None) is not None:
+            self.stop_rotation()
         if getattr(self, "_h", None):
             for b in self._buffers:
                 b.free()

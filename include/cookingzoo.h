@@ -100,6 +100,22 @@ int cz_load_recipes(cz_handle h, const uint32_t *table, int32_t n_recipes, int32
  * order and per-class list order that get_feature_vector (cooking_env.py:352-373) iterates. */
 int cz_load_layouts(cz_handle h, const uint32_t *init_records, const uint32_t *obs_desc, int32_t n_layouts);
 
+/* Fresh layouts under a stepping batch (the reference draws a new level at every reset, cooking_env.py:191-195,
+ * parsing.py:21-151; the device redraws from the resident pool).  cz_update_layouts replaces pool slots
+ * [first, first + count) - same formats as cz_load_layouts - without touching the handle's stream: the tables stay where they
+ * are, the caller's arrays are free again on return, and the copy runs on a stream of the library's own, ordered after
+ * every step issued so far and not waited for by later steps.  Never replace slots that envs can still draw or are still
+ * playing on: cz_set_layout_group(h, groups, active) cuts every env's pool slice into `groups` equal parts and lets the envs
+ * draw their next episodes from part `active` only (1, 0 = the whole slice, the default), from the next step on (stream
+ * order); it waits - on the device - for the updates issued so far, so no env draws a half-written slot.  Rotation:
+ * switch to part b; issue at least max_steps + 1 more steps (every episode that started on part a has ended); update
+ * part a; ... (cooking_zoo_amd.vec_env.CookingVecEnv.rotate_layouts does this from a background thread).  Every pool slice's
+ * length must be a multiple of `groups`.  cz_update_layouts with count 0 only creates the copy stream and the staging block
+ * (so that the first real update does not pay for them).  cz_layout_updates: slots replaced so far. */
+int cz_update_layouts(cz_handle h, int32_t first, int32_t count, const uint32_t *init_records, const uint32_t *obs_desc);
+int cz_set_layout_group(cz_handle h, int32_t groups, int32_t active);
+int64_t cz_layout_updates(cz_handle h);
+
 /* ---- state ----------------------------------------------------------------------------------------- */
 int cz_set_state(cz_handle h, int64_t env_begin, int64_t env_count, const uint32_t *records);
 int cz_get_state(cz_handle h, int64_t env_begin, int64_t env_count, uint32_t *records);
@@ -195,6 +211,9 @@ int cz_rollout(cz_handle h, int32_t T, uint64_t seed, uint32_t step0, double *d_
 uint32_t cz_action(uint64_t seed, int64_t env_global, int32_t agent, uint32_t step, uint32_t n_actions);
 /* the layout an env draws for its k-th episode under auto_reset */
 uint32_t cz_next_layout(int64_t env_global, uint32_t episode, uint32_t pool_word, uint32_t n_layouts);
+/* ... when the envs draw from part `active` of `groups` (cz_set_layout_group) */
+uint32_t cz_next_layout_group(int64_t env_global, uint32_t episode, uint32_t pool_word, uint32_t n_layouts, uint32_t groups,
+                              uint32_t active);
 
 /* ---- device memory + timing helpers (so the Python host needs no torch) ----------------------------- */
 void *cz_dev_alloc(cz_handle h, size_t bytes);

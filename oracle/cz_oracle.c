@@ -741,6 +741,8 @@ typedef struct {
     const czo_meta_entry *meta;
     int n_meta;
     int64_t env_id_base;              /* global id of env 0 (shard offset) */
+    int32_t pool_groups, pool_active; /* auto-reset draws come from part pool_active of every pool slice cut into pool_groups
+                                         equal parts (0 or 1 groups: the whole slice) -- mirrors cz_set_layout_group */
 } czo_ctx;
 
 static void recompute_marks(const czo_ctx *cx, World *w, uint32_t *rec)
@@ -759,6 +761,13 @@ uint32_t czo_next_layout(int64_t env_global, uint32_t episode, uint32_t pool_wor
 {
     uint32_t base = pool_word & 0xFFFFu, count = pool_word >> 16;
     if (count == 0) { base = 0; count = num_layouts; }
+    return base + (uint32_t)(((uint64_t)env_global + (uint64_t)episode * 7919u) % count);
+}
+uint32_t czo_next_layout_group(int64_t env_global, uint32_t episode, uint32_t pool_word, uint32_t num_layouts, uint32_t groups, uint32_t active)
+{
+    uint32_t base = pool_word & 0xFFFFu, count = pool_word >> 16;
+    if (count == 0) { base = 0; count = num_layouts; }
+    if (groups > 1) { count /= groups; base += active * count; }
     return base + (uint32_t)(((uint64_t)env_global + (uint64_t)episode * 7919u) % count);
 }
 
@@ -803,7 +812,8 @@ int czo_step_env(const czo_ctx *cx, int64_t env_local, uint32_t *rec, const int3
         if (cfg->auto_reset) {
             uint32_t ep = rec[W_EPISODE] + 1;
             rec[W_EPISODE] = ep;
-            uint32_t lay = czo_next_layout(cx->env_id_base + env_local, ep, rec[W_POOL], (uint32_t)cfg->num_layouts);
+            uint32_t lay = czo_next_layout_group(cx->env_id_base + env_local, ep, rec[W_POOL], (uint32_t)cfg->num_layouts,
+                                                 (uint32_t)cx->pool_groups, (uint32_t)cx->pool_active);
             int e = czo_reset_env(cx, env_local, lay, rec, obs);
             for (int a = 0; a < A; ++a) { rewards[a] = 0.0; term[a] = 0; trunc[a] = 0; }
             return e;

@@ -33,7 +33,8 @@ class CzoMeta(C.Structure):
 
 class CzoCtx(C.Structure):
     _fields_ = [("cfg", C.POINTER(CzoConfig)), ("recipe_table", C.c_void_p), ("layouts", C.POINTER(CzoLayout)),
-                ("meta", C.POINTER(CzoMeta)), ("n_meta", C.c_int), ("env_id_base", C.c_int64)]
+                ("meta", C.POINTER(CzoMeta)), ("n_meta", C.c_int), ("env_id_base", C.c_int64),
+                ("pool_groups", C.c_int32), ("pool_active", C.c_int32)]
 
 
 def load_lib():
@@ -83,7 +84,20 @@ class Oracle:
             self.layout_arr[i] = CzoLayout(rec.ctypes.data, off.ctypes.data, cells.ctypes.data)
         self.meta_arr = (CzoMeta * len(meta))(*[CzoMeta(meta_class_id(k), int(v)) for k, v in meta.items()])
         self.ctx = CzoCtx(C.pointer(self.cfg), self.recipe_table.ctypes.data, self.layout_arr, self.meta_arr,
-                          len(meta), int(env_id_base))
+                          len(meta), int(env_id_base), 1, 0)
+
+    def set_layout(self, i, rec, off, cells):
+        """replace layout i of the pool (mirror of cz_update_layouts)"""
+        rec = np.ascontiguousarray(rec, dtype=np.uint32)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        cells = np.ascontiguousarray(cells, dtype=np.int16)
+        assert rec.size == self.dims.RW
+        self._keep += [rec, off, cells]                  # (the replaced arrays stay alive too: cheap, and nothing can dangle)
+        self.layout_arr[i] = CzoLayout(rec.ctypes.data, off.ctypes.data, cells.ctypes.data)
+
+    def set_layout_group(self, groups, active):
+        """mirror of cz_set_layout_group"""
+        self.ctx.pool_groups, self.ctx.pool_active = int(groups), int(active)
 
     def _p(self, a):
         return a.ctypes.data_as(C.c_void_p) if a is not None else None
@@ -191,6 +205,21 @@ class VecOracle:
         err, obs, rew, term, trunc, _ = self.oracle.rollout(self.records, T, seed, step0, want_obs)
         assert err == 0, err
         return obs, rew, term, trunc
+
+    # ---- the layout rotation of CookingVecEnv.rotate_layouts, mirrored (tests apply the env's `rotation_events` here)
+    def update_layouts(self, first, layouts):
+        for k, l in enumerate(layouts):
+            off, cells = l.static_table()
+            self.oracle.set_layout(first + k, l.init_record(self.dims, first + k), off, cells)
+
+    def set_layout_group(self, groups, active):
+        self.oracle.set_layout_group(groups, active)
+
+    def apply_rotation_event(self, ev):
+        if ev[1] == "group":
+            self.set_layout_group(ev[2], ev[3])
+        else:
+            self.update_layouts(ev[2], ev[3])
 
 
 class ShardedOracle:
