@@ -416,7 +416,10 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
             const bool sely = code == 2 || (code >= 5 && (code & 1) && (code - 5) / 2 != a);
             submask[l] = (selx ? 0x7F8u : 0u) | (sely ? 0x7F8u << 16 : 0u);
         }
-        CREATE_CHK(hipMalloc(&h->d_lut, sizeof lut + sizeof submask));
+        // ... followed by the despawn / respawn parameters (SpawnCfg, cz_set_spawn; all zero: switched off)
+        static_assert(SPAWN_CFG_OFFSET == sizeof lut + sizeof submask, "layout of the block behind Params::lut");
+        CREATE_CHK(hipMalloc(&h->d_lut, sizeof lut + sizeof submask + sizeof(SpawnCfg)));
+        CREATE_CHK(hipMemset(h->d_lut, 0, sizeof lut + sizeof submask + sizeof(SpawnCfg)));
         CREATE_CHK(hipMemcpy(h->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
         CREATE_CHK(hipMemcpy((char *)h->d_lut + sizeof lut, submask, sizeof submask, hipMemcpyHostToDevice));
         P.lut = h->d_lut;
@@ -481,6 +484,38 @@ extern "C" int cz_set_stream(cz_handle h, void *hip_stream) {
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     h->tables_version++;
     return 0;
+}
+// Agent despawn / respawn for every world of the batch, on the device (cooking_world.py:267-290): from the next reset on.
+// rates 0 / 0 switch it off.  spawn_x / spawn_y: per agent the candidate coordinates of its spawn area (the level file's
+// AGENTS entries, parsing.py:118-151), 32 bytes each, n_x / n_y of them used.
+extern "C" int cz_set_spawn(cz_handle h, double despawn_rate, double respawn_rate, int32_t grace_period, uint64_t seed,
+                            const uint8_t *spawn_x, const int32_t *n_x, const uint8_t *spawn_y, const int32_t *n_y) {
+    if (!h) return fail(nullptr, "null handle");
+    const bool on = despawn_rate > 0.0 || respawn_rate > 0.0;
+    if (despawn_rate < 0.0 || respawn_rate < 0.0 || grace_period < 0 || grace_period > SPAWN_MAX_GRACE)
+        return fail(h, "cz_set_spawn: rates must be >= 0 and 0 <= grace_period <= %d (five bits per agent in the record's status word)", SPAWN_MAX_GRACE);
+    SpawnCfg cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.seed = seed; cfg.despawn_rate = despawn_rate; cfg.respawn_rate = respawn_rate; cfg.grace_period = (uint32_t)grace_period;
+    if (on) {
+        if (!spawn_x || !n_x || !spawn_y || !n_y) return fail(h, "cz_set_spawn: spawn areas missing");
+        for (int a = 0; a < h->P.A; ++a) {
+            if (n_x[a] < 1 || n_x[a] > 32 || n_y[a] < 1 || n_y[a] > 32) return fail(h, "cz_set_spawn: agent %d: 1..32 x and y candidates", a);
+            cfg.area[a].nx = (uint8_t)n_x[a]; cfg.area[a].ny = (uint8_t)n_y[a];
+            memcpy(cfg.area[a].xs, spawn_x + 32 * a, 32); memcpy(cfg.area[a].ys, spawn_y + 32 * a, 32);
+        }
+    }
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy((char *)h->d_lut + SPAWN_CFG_OFFSET, &cfg, sizeof cfg, hipMemcpyHostToDevice));
+    h->P.auto_reset = (h->P.auto_reset & 1) | (on ? 2 : 0);
+    h->tables_version++;
+    return 0;
+}
+// the draw the device takes (host mirror, for parity tests): uniform in [0, 1), keyed by (seed, global env id, episode << 32 | t,
+// agent, draw index)
+extern "C" double cz_spawn_uniform(uint64_t seed, int64_t env_global, uint32_t episode, uint32_t t, int32_t agent, uint32_t draw) {
+    return spawn_uniform(seed, (uint64_t)env_global, ((uint64_t)episode << 32) | (uint64_t)t, (uint32_t)agent, draw);
 }
 extern "C" int32_t cz_record_words(cz_handle h) { return h ? h->P.RW : 0; }
 extern "C" int cz_sync(cz_handle h) {

@@ -147,6 +147,37 @@ __host__ __device__ inline uint32_t next_layout(int64_t env_global, uint32_t epi
 constexpr int LAY_CTL_WORDS = 16;
 enum : uint32_t { LC_GROUPS = 0, LC_ACTIVE = 1 };
 
+// ---- agent despawn / respawn on the device (cooking_world.py:267-290 handle_agent_spawn, parsing.py:154-167 generate_location).
+// The reference draws from numpy's process-global stream, which defines the draws of ONE world per process; a batch takes every
+// draw from a counter-based stream keyed by (seed, global env id, episode << 32 | t, agent, draw index) instead - the same
+// function as cooking_zoo_amd/spawn.py `uniform` - so results depend neither on the batch size nor on the sharding nor on how
+// the steps are launched (one per launch, overlapped, fused).  Per agent the record's status word carries, from bit 8 + 6 a:
+// 1 bit "despawned" and 5 bits of grace countdown.  The parameters live in device memory behind the quotient table.
+struct SpawnCfg {
+    uint64_t seed;
+    double despawn_rate, respawn_rate;
+    uint32_t grace_period, pad;
+    struct Area { uint8_t nx, ny, pad[2]; uint8_t xs[32], ys[32]; } area[MAX_AGENTS];      // the level file's spawn areas (parsing.py:118-151)
+};
+constexpr uint32_t SPAWN_CFG_OFFSET = 256 * 8 + 64 * 4;      // bytes behind Params::lut: the 256 doubles and the 64 submask words
+constexpr int SPAWN_SHIFT0 = 8, SPAWN_BITS = 6, SPAWN_MAX_GRACE = 31;
+__host__ __device__ inline uint32_t spawn_initial_status(uint32_t grace_period, int n_agents) {   // everybody present, grace running
+    uint32_t st = 0;
+    for (int a = 0; a < n_agents; ++a) st |= grace_period << (SPAWN_SHIFT0 + SPAWN_BITS * a + 1);
+    return st;
+}
+__host__ __device__ inline uint64_t spawn_mix(uint64_t x) {                      // splitmix64 finaliser
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline double spawn_uniform(uint64_t seed, uint64_t env_global, uint64_t step_key, uint32_t agent, uint32_t draw) {
+    uint64_t k = spawn_mix(seed + 0x9E3779B97F4A7C15ull * env_global);
+    k = spawn_mix(k ^ (step_key * 0xD1B54A32D192ED03ull));
+    k = spawn_mix(k ^ ((uint64_t)agent << 32) ^ (uint64_t)draw);
+    return (double)(k >> 11) * (1.0 / 9007199254740992.0);
+}
+
 // wave-uniform bit set over N*64 positions (object slots or grid cells)
 template <int N>
 struct Mask {
@@ -659,6 +690,54 @@ struct Ops {
                 e.agw = wrl((A & 0x00FFFFFFu) | ((uint32_t)((me.h + 1) & 0xFF) << 24), a, e.agw);   // only the hands can change
             }
         }
+    }
+
+    // cooking_world.py:267-290 handle_agent_spawn for this world, agents in index order; returns the agents that left in this
+    // step (bit a; they are reported truncated once, cooking_env.py:344-349).  Everything here is wave-uniform scalar work,
+    // executed only by batches that have despawn / respawn switched on (cz_set_spawn).
+    static __device__ __forceinline__ uint32_t handle_agent_spawn(E &e, const Ctx &cx, const SpawnCfg *cfg_generic, int64_t env_global) {
+        typedef const __attribute__((address_space(4))) SpawnCfg *kcfg;
+        const kcfg cfg = (kcfg)cfg_generic;
+        const uint64_t seed = cfg->seed, key = ((uint64_t)e.episode << 32) | (uint64_t)e.t;
+        const double despawn_rate = cfg->despawn_rate, respawn_rate = cfg->respawn_rate;
+        uint32_t st = e.status, gone = 0u;
+        uint32_t gone_bits = 0u;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) gone_bits |= 1u << (SPAWN_SHIFT0 + SPAWN_BITS * a);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int sh = SPAWN_SHIFT0 + SPAWN_BITS * a;
+            if ((st >> (sh + 1)) & 31u) { st -= 1u << (sh + 1); continue; }          // agent_grace_period[i] -= 1
+            const bool despawned = (st >> sh) & 1u;
+            if (!despawned) {
+                const int n_active = NA - __popc(st & gone_bits);
+                if (n_active > 1 && spawn_uniform(seed, (uint64_t)env_global, key, (uint32_t)a, 0u) < despawn_rate) {
+                    if ((rdl(e.agw, a) >> 24) == 0u) {                                // despawn_agent: an agent that holds something stays
+                        st |= 1u << sh;
+                        gone |= 1u << a;
+                    }
+                }
+            } else if (spawn_uniform(seed, (uint64_t)env_global, key, (uint32_t)a, 1u) < respawn_rate) {
+                // respawn_agent: back, grace period restarted, on a Floor cell of its spawn area that nobody - active or
+                // not, itself included - stands on (generate_location: up to 1001 tries)
+                st = (st & ~(63u << sh)) | (cfg->grace_period << (sh + 1));
+                const uint32_t nx = cfg->area[a].nx, ny = cfg->area[a].ny;
+#pragma nounroll
+                for (uint32_t k = 0; k < 1001u; ++k) {
+                    const uint32_t ix = (uint32_t)(spawn_uniform(seed, (uint64_t)env_global, key, (uint32_t)a, 2u + 2u * k) * (double)nx);
+                    const uint32_t iy = (uint32_t)(spawn_uniform(seed, (uint64_t)env_global, key, (uint32_t)a, 3u + 2u * k) * (double)ny);
+                    const uint32_t x = cfg->area[a].xs[ix], y = cfg->area[a].ys[iy];
+                    if (x >= (uint32_t)cx.W || y >= (uint32_t)cx.H) continue;
+                    if ((cell_at(e, (int)(y * (uint32_t)cx.W + x)) & CELL_TYPE) != FLOOR) continue;
+                    const uint32_t xy = x | (y << 8);
+                    if (ballot((e.agw & 0xFFFFu) == xy) & ((1ull << NA) - 1ull)) continue;
+                    e.agw = wrl((rdl(e.agw, a) & 0xFFFF0000u) | xy, a, e.agw);         // the location only (cooking_world.py:290)
+                    break;
+                }
+            }
+        }
+        e.status = st;
+        return gone;
     }
 
     // cooking_world.py:77-88 progress_world (+ Blender.process world_objects.py:321-335, BlenderFood.blend

@@ -369,6 +369,7 @@ struct StepOut {
     uint32_t term, trunc;
     bool stepped, finished;        // a world step was executed / it ended the episode
     bool header;                   // a header word other than `t` changed (marks, status, episode, layout)
+    uint32_t gone;                 // despawn / respawn: bit a = agent a left in this step (reported truncated once)
 };
 
 // One accumulated_step (cooking_env.py:243-269) of one env held in registers.
@@ -377,10 +378,13 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
                                          int64_t env_global, uint32_t &rowv, Lds<CPL> &lds, uint32_t (&dsc)[OBS_CHUNK], Dirty &dt, StepOut &o) {
     using O = Ops<OPL, CPL, NA, SCHEME>;
     o.myrew = 0.0;
-    o.term = 0; o.trunc = 0; o.stepped = false; o.finished = false; o.header = false;
+    o.term = 0; o.trunc = 0; o.stepped = false; o.finished = false; o.header = false; o.gone = 0u;
+    // P.auto_reset: bit 0 = next-step auto-reset, bit 1 = agent despawn / respawn is on (cz_set_spawn)
+    const bool spawning = (P.auto_reset & 2) != 0;
+    const SpawnCfg *const spawn_cfg = reinterpret_cast<const SpawnCfg *>(reinterpret_cast<const char *>(P.lut) + SPAWN_CFG_OFFSET);
     if (e.status & ST_DONE) {
         o.header = true;
-        if (P.auto_reset) {
+        if (P.auto_reset & 1) {
             // next-step autoreset: reset() of cooking_env.py:178-210 from the layout pool
             e.episode += 1;
             const uint32_t *const lay0 = late_params(kp_off)->lay_init;
@@ -391,6 +395,10 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
             uint32_t recipes = e.recipes, episode = e.episode, pool = e.pool;
             load_env(P, e, cx, lay0 + (size_t)lay * P.RW);
             e.t = 0; e.layout = lay; e.status = 0; e.episode = episode; e.recipes = recipes; e.pool = pool;
+            if (spawning) {       // a fresh world: everybody present, grace periods running (load_level.py:67-68, parsing.py:142)
+                typedef const __attribute__((address_space(4))) SpawnCfg *kcfg;
+                e.status = spawn_initial_status(((kcfg)spawn_cfg)->grace_period, NA);
+            }
             all_marks(P, e, cx, rowv, lds);
             if (P.obs) load_desc(P, lay, 0, cx.lane, dsc);
             dt.cells = 1; dt.touched = 1; dt.interacted = 1;          // everything must be written back
@@ -402,13 +410,19 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
     }
     o.stepped = true;
     e.t += 1;                                                        // cooking_env.py:244
+    // a despawned agent is not in the list world_step acts on (cooking_world.py:105-108): action -1
+    if (spawning) acts = (cx.lane < NA && ((e.status >> (SPAWN_SHIFT0 + SPAWN_BITS * cx.lane)) & 1u)) ? 0xFFFFFFFFu : acts;
 #if defined(CZ_PROFILE)
     const int lane = cx.lane; const long long env = env_global - P.env_id_base;
 #endif
     O::perform_agent_actions(e, cx, acts, dt);                      // cooking_world.py:104-108
     CZ_STAMP(2);
     O::progress_and_link(e, cx, dt);
-    CZ_STAMP(3);                                // :109-110 (handle_agent_spawn: neutral at rate 0)
+    if (spawning) {                             // :109-110 handle_agent_spawn
+        o.gone = O::handle_agent_spawn(e, cx, spawn_cfg, env_global);
+        o.header = true;                        // (the grace counters live in the status word)
+    }
+    CZ_STAMP(3);
     // compute_rewards cooking_env.py:290-315
     const bool truncated = (int)e.t >= P.max_steps;                 // compute_truncated :333-350
     const uint32_t before = e.marks;
@@ -447,7 +461,7 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
                     if (cx.lane == r && r < NA) o.myrew = x;
                 }
             }
-            o.header = lo != e.marks || hi != e.marks_hi;
+            o.header |= lo != e.marks || hi != e.marks_hi;
             e.marks = lo; e.marks_hi = hi;
         }
         // recipe roots are bit 0 of each 16-bit field
@@ -500,7 +514,7 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
             }
         }
         e.marks = after;
-        o.header = after != before;
+        o.header |= after != before;
         // recipe roots are bit 0 of each marks byte
         const uint32_t roots = after & 0x01010101u & (P.R >= 4 ? 0xFFFFFFFFu : ((1u << (8 * P.R)) - 1u));
         done = P.end_all ? (__popc(roots) == P.R) : (roots != 0u);
@@ -694,7 +708,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
                 // (write-through in an overlapped run: the next launch rewrites the same bytes, possibly from another XCD)
                 if (!FUSED || rewards) strec<double>(chained, rewards, oidx * 8u, myrew);
                 if (!FUSED || term) strec<uint8_t>(chained, term, oidx, (uint8_t)o.term);
-                if (!FUSED || trunc) strec<uint8_t>(chained, trunc, oidx, (uint8_t)o.trunc);
+                if (!FUSED || trunc) strec<uint8_t>(chained, trunc, oidx, (uint8_t)(o.trunc | ((o.gone >> lane) & 1u)));
             }
         }
         if (!FUSED) {
@@ -788,6 +802,8 @@ __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin,
     const uint32_t old_episode = rfl(rec[W_EPISODE]);
     load_env(P, e, cx, P.lay_init + (size_t)lay * P.RW);
     e.t = 0; e.layout = lay; e.status = 0; e.episode = old_episode; e.recipes = rfl(recipe_words[i]);
+    if (P.auto_reset & 2)
+        e.status = spawn_initial_status(rfl(reinterpret_cast<const SpawnCfg *>(reinterpret_cast<const char *>(P.lut) + SPAWN_CFG_OFFSET)->grace_period), NA);
     e.pool = rfl(pool_words[i]);
     uint32_t rowv = load_recipe_rows(P, e.recipes, lane);
     all_marks(P, e, cx, rowv, lds);

@@ -1,4 +1,8 @@
-"""Agent despawn / respawn bookkeeping for a BATCH of worlds (host side).
+"""Agent despawn / respawn bookkeeping for a BATCH of worlds: the host-side MODEL of what the step kernels do.
+
+The product path evaluates this rule on the device (cz_set_spawn, Ops::handle_agent_spawn in csrc/cz_device.h); this module is
+the same rule in numpy, used by the tests (against a scalar transliteration of the reference, and against the device) and by
+`CookingVecEnv.spawn` only as a read-only view of the device's bookkeeping.
 
 The reference does this per world in `CookingWorld.handle_agent_spawn` (+ `despawn_agent` / `respawn_agent`,
 cooking_world.py:267-290) with draws from numpy's process-global stream and respawn cells from Python's global `random`
@@ -6,8 +10,8 @@ cooking_world.py:267-290) with draws from numpy's process-global stream and resp
 (environment/cooking_env.py) reproduces exactly that and is pinned to the reference.  For thousands of worlds this module
 keeps the same RULE per world -- grace countdown, at most one Bernoulli draw per agent and step, an agent that holds
 something stays, a respawned agent lands on a free Floor cell of its spawn area -- but takes every draw from a
-counter-based stream keyed by (seed, global env id, step, agent, draw index), so results do not depend on the batch
-size, the sharding over GPUs or the order worlds are processed in.  The device learns who acts through action -1
+counter-based stream keyed by (seed, global env id, episode << 32 | t of that world, agent, draw index), so results do not
+depend on the batch size, the sharding over GPUs, the order worlds are processed in or the form the steps are launched in.  The device learns who acts through action -1
 (cooking_world.py:105-108); this class only edits agent positions in the env records of worlds where somebody respawns.
 """
 from __future__ import annotations
@@ -71,6 +75,9 @@ class SpawnBook:
         edited in place: write them back)."""
         self.step += 1
         stepped = np.ones(self.N, dtype=bool) if stepped is None else np.asarray(stepped, dtype=bool)
+        # the key of this step's draws, per world: its episode and step counter (after the step)
+        key = (records[:, soa.W_EPISODE].astype(np.uint64) << np.uint64(32)) | records[:, soa.W_T].astype(np.uint64)
+        self._key = key
         self.changed[stepped] = False                                        # cooking_world.py:106
         aw0 = soa.AGENT_WORD0
         moved = np.zeros(self.N, dtype=bool)
@@ -79,14 +86,14 @@ class SpawnBook:
             self.grace[graced, i] -= 1
             free = stepped & ~graced
             cand_d = free & (self.active.sum(axis=1) > 1) & self.active[:, i]
-            u1 = uniform(self.seed, self.env_ids, self.step, i, 0)
+            u1 = uniform(self.seed, self.env_ids, key, i, 0)
             hit = cand_d & (u1 < self.despawn_rate)
             holding = ((records[:, aw0 + i] >> np.uint32(24)) & np.uint32(0xFF)) != 0
             gone = hit & ~holding                                            # an agent that holds something stays (:280-281)
             self.active[gone, i] = False
             self.changed[gone, i] = True
             cand_r = free & ~cand_d & ~self.active[:, i] & ~gone              # the `elif` arm: only when the first test was not taken
-            u2 = uniform(self.seed, self.env_ids, self.step, i, 1)
+            u2 = uniform(self.seed, self.env_ids, key, i, 1)
             back = cand_r & (u2 < self.respawn_rate)
             for e in np.nonzero(back)[0]:
                 x, y = self._generate_location(records[e], dims, i, int(e))
@@ -104,8 +111,8 @@ class SpawnBook:
         cells = soa.record_cells(dims, rec)
         taken = {soa.unpack_agent(rec[soa.AGENT_WORD0 + a])[:2] for a in range(dims.A)}
         for k in range(1001):
-            ux = uniform(self.seed, self.env_ids[e], self.step, agent, 2 + 2 * k)
-            uy = uniform(self.seed, self.env_ids[e], self.step, agent, 3 + 2 * k)
+            ux = uniform(self.seed, self.env_ids[e], self._key[e], agent, 2 + 2 * k)
+            uy = uniform(self.seed, self.env_ids[e], self._key[e], agent, 3 + 2 * k)
             x, y = xs[int(ux * len(xs))], ys[int(uy * len(ys))]
             if 0 <= x < dims.W and 0 <= y < dims.H and (x, y) not in taken and (cells[y * dims.W + x] & soa.CELL_TYPE_MASK) == soa.FLOOR:
                 return int(x), int(y)
@@ -114,3 +121,28 @@ class SpawnBook:
     def relevant(self):
         """[N, A] bool: the agents a step reports on (active, or despawned in this very step): cooking_world.py:292-293"""
         return self.active | self.changed
+
+
+# ---- the device's encoding of this bookkeeping in record word W_STATUS (csrc/cz_device.h SPAWN_*): from bit 8 + 6 a one
+# "despawned" bit and five bits of grace countdown per agent
+SPAWN_SHIFT0, SPAWN_BITS, SPAWN_MAX_GRACE = 8, 6, 31
+
+
+def status_bits(active, grace):
+    """[N, A] bool active, [N, A] int grace -> uint32 [N] to be or-ed into the status word"""
+    out = np.zeros(active.shape[0], dtype=np.uint32)
+    for a in range(active.shape[1]):
+        out |= ((~active[:, a]).astype(np.uint32) | (grace[:, a].astype(np.uint32) << np.uint32(1))) << np.uint32(SPAWN_SHIFT0 + SPAWN_BITS * a)
+    return out
+
+
+def decode_status(status, num_agents):
+    """uint32 [N] status words -> (active [N, A] bool, grace [N, A] int64)"""
+    status = np.asarray(status, dtype=np.uint32)
+    active = np.empty((status.shape[0], num_agents), dtype=bool)
+    grace = np.empty((status.shape[0], num_agents), dtype=np.int64)
+    for a in range(num_agents):
+        f = (status >> np.uint32(SPAWN_SHIFT0 + SPAWN_BITS * a)) & np.uint32(63)
+        active[:, a] = (f & 1) == 0
+        grace[:, a] = f >> 1
+    return active, grace

@@ -98,6 +98,33 @@ def resolve_recipe_tables(recipes):
     return book, list(book.keys())
 
 
+class SpawnView:
+    """Read-only view of the device's despawn / respawn bookkeeping (record word W_STATUS, cz_set_spawn): `active` [N, A],
+    `grace` [N, A] as of the last `refresh()` (every host-array `step` / `reset` refreshes), `changed` [N, A] = whose
+    presence flipped between the last two refreshes of a running episode (cooking_world.py status_changed)."""
+
+    def __init__(self, env):
+        self._env = env
+        self.active = np.ones((env.num_envs, env.num_agents), dtype=bool)
+        self.grace = np.full((env.num_envs, env.num_agents), env._spawn_cfg[2], dtype=np.int64)
+        self.changed = np.zeros((env.num_envs, env.num_agents), dtype=bool)
+        self._episode = None
+
+    def refresh(self, reset=False):
+        from cooking_zoo_amd.spawn import decode_status
+        recs = self._env.get_state()
+        active, grace = decode_status(recs[:, soa.W_STATUS], self._env.num_agents)
+        episode = recs[:, soa.W_EPISODE].copy()
+        same = (not reset) and self._episode is not None
+        self.changed = (active != self.active) & (episode == self._episode)[:, None] if same else np.zeros_like(active)
+        self.active, self.grace, self._episode = active, grace, episode
+        return self
+
+    def relevant(self):
+        """[N, A] bool: the agents a step reports on (active, or despawned in this very step): cooking_world.py:292-293"""
+        return self.active | self.changed
+
+
 class CookingVecEnv:
     def __init__(self, num_envs, level, meta_file, num_agents, max_steps, recipes, end_condition_all_dishes=False,
                  action_scheme="scheme1", reward_scheme=None, *, num_layouts=256, layout_seed=0, layouts=None,
@@ -111,8 +138,9 @@ class CookingVecEnv:
         (overwritten by the next call) instead of fresh arrays -- the copy engines then write them directly, which is what
         a host-array step of thousands of envs spends its time on (18 MB of observations per step at 4096 envs).
         `agent_despawn_rate` / `agent_respawn_rate` / `grace_period`: agent despawn / respawn (cooking_world.py:267-290)
-        for every world of the batch, host-side bookkeeping with keyed random streams (cooking_zoo_amd/spawn.py); only the
-        host-array `step` applies it."""
+        for every world of the batch, evaluated by the step kernels themselves with keyed random streams (cz_set_spawn) -
+        on every stepping path (`step`, `step_device`, `step_device_ring`, `rollout`).  `self.spawn` is a read-only view of
+        that bookkeeping (`active`, `grace`, and after a host-array `step` also `changed`)."""
         self._pinned = bool(pinned_outputs)
         self._pin_bufs = {}
         self._spawn_cfg = (float(agent_despawn_rate), float(agent_respawn_rate), int(grace_period), int(spawn_seed))
@@ -194,15 +222,21 @@ class CookingVecEnv:
         self._rot = None                      # rotate_layouts state
         self.rotation_events = []             # (step index, "group", groups, active) / (step index, "layouts", first slot, [Layout])
         if self._spawn_cfg[0] or self._spawn_cfg[1]:
-            from cooking_zoo_amd.spawn import SpawnBook
             if len(self.levels) != 1:
                 raise ValueError("agent despawn / respawn needs one level per batch (the spawn areas come from the level file)")
             cells = [(spec["X_POSITION"], spec["Y_POSITION"]) for spec in self.level_objects[0]["AGENTS"]
                      for _ in range(spec["MAX_COUNT"])][:self.num_agents]                       # parsing.py:145
-            self.spawn = SpawnBook(self.num_envs, self.num_agents, cells, despawn_rate=self._spawn_cfg[0],
-                                   respawn_rate=self._spawn_cfg[1], grace_period=self._spawn_cfg[2], seed=self._spawn_cfg[3],
-                                   env_id_base=self.env_id_base)
-            self._episode_seen = None
+            self.spawn_cells = [(list(xs), list(ys)) for xs, ys in cells]
+            sx, sy = np.zeros((self.num_agents, 32), dtype=np.uint8), np.zeros((self.num_agents, 32), dtype=np.uint8)
+            nx, ny = np.zeros(self.num_agents, dtype=np.int32), np.zeros(self.num_agents, dtype=np.int32)
+            for a, (xs, ys) in enumerate(self.spawn_cells):
+                if not (1 <= len(xs) <= 32 and 1 <= len(ys) <= 32):
+                    raise ValueError("a spawn area lists 1..32 x and y candidates")
+                nx[a], ny[a] = len(xs), len(ys)
+                sx[a, :len(xs)], sy[a, :len(ys)] = xs, ys
+            _native.check(self._h, L.cz_set_spawn(self._h, self._spawn_cfg[0], self._spawn_cfg[1], self._spawn_cfg[2], self._spawn_cfg[3],
+                                                  _ptr(sx), _ptr(nx), _ptr(sy), _ptr(ny)))
+            self.spawn = SpawnView(self)
 
     # ------------------------------------------------------------------ tables
     def _upload_layouts(self):
@@ -351,10 +385,7 @@ class CookingVecEnv:
         rid = np.ascontiguousarray(self.recipe_ids[env_begin:env_begin + n])
         _native.check(self._h, _native.lib().cz_reset(self._h, env_begin, n, _ptr(ids), _ptr(rid), _ptr(pools), _ptr(obs)))
         if self.spawn is not None:
-            mask = np.zeros(self.num_envs, dtype=bool)
-            mask[env_begin:env_begin + n] = True
-            self.spawn.reset_envs(mask)
-            self._episode_seen = None if n == self.num_envs else self._episode_seen
+            self.spawn.refresh(reset=True)
         return obs
 
     def _host_array(self, key, shape, dtype):
@@ -382,42 +413,15 @@ class CookingVecEnv:
         acts[...] = np.asarray(actions).reshape(N, A)
         if acts.size and int(acts.max()) >= self.n_actions:
             raise ValueError(f"actions must be in [0, {self.n_actions}) for {self.action_scheme} (negative = despawned agent)")
-        if self.spawn is not None:
-            acts[...] = self.spawn.mask_actions(acts)                     # despawned agents do not act
         obs = self._host_array("obs", (N, A, self.F), np.float64) if return_obs else None
         rew = self._host_array("rew", (N, A), np.float64)
         term = self._host_array("term", (N, A), np.uint8)
         trunc = self._host_array("trunc", (N, A), np.uint8)
         _native.check(self._h, _native.lib().cz_step(self._h, _ptr(acts), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc)))
         if self.spawn is not None:
-            self._spawn_after_step(obs, trunc)
+            self.spawn.refresh()                                          # (the kernel did the bookkeeping: this only reads it back)
         self._advance(1)
         return obs, rew, term, trunc
-
-    def _spawn_after_step(self, obs, trunc):
-        """handle_agent_spawn (cooking_world.py:267-290) of every world that executed a world step in this launch; worlds
-        that were re-instantiated by it (auto-reset pass) start over with everybody present."""
-        recs = self.get_state()
-        episode = recs[:, soa.W_EPISODE].copy()
-        done_now = (recs[:, soa.W_STATUS] & soa.STATUS_DONE) != 0
-        if self._episode_seen is None:
-            fresh = was_done = np.zeros(self.num_envs, dtype=bool)
-        else:
-            fresh, was_done = episode != self._episode_seen[0], self._episode_seen[1]
-        self._episode_seen = (episode, done_now)
-        self.spawn.reset_envs(fresh)
-        moved = self.spawn.after_step(recs, self.dims, stepped=~fresh & ~was_done)
-        for e in moved:
-            self.set_state(recs[e:e + 1], env_begin=int(e))
-            if obs is not None:
-                obs[e] = self._observe_fresh(int(e))                     # somebody was put on a new cell
-        # whoever was despawned in this step is reported once, truncated (cooking_env.py:344-349)
-        trunc |= (self.spawn.changed & ~self.spawn.active).astype(np.uint8)
-
-    def _observe_fresh(self, e):
-        out = np.empty((1, self.num_agents, self.F), dtype=np.float64)
-        _native.check(self._h, _native.lib().cz_observe(self._h, e, 1, _ptr(out)))
-        return out[0]
 
     def last_marks(self):
         """Recipe-node marks after the most recent host-array `step`: uint64 [N], bit 8r + j = node j of the env's r-th

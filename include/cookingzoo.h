@@ -116,6 +116,20 @@ int cz_update_layouts(cz_handle h, int32_t first, int32_t count, const uint32_t 
 int cz_set_layout_group(cz_handle h, int32_t groups, int32_t active);
 int64_t cz_layout_updates(cz_handle h);
 
+/* Agent despawn / respawn (cooking_world.py:267-290 handle_agent_spawn, despawn_agent, respawn_agent; parsing.py:154-167
+ * generate_location) for every world of the batch, evaluated by the step kernels themselves - on every path: cz_step,
+ * cz_step_device*, overlapped runs, cz_rollout.  The reference takes its draws from numpy's process-global stream, which
+ * defines them for one world per process; here every draw comes from a counter-based stream keyed by (seed, global env id,
+ * episode << 32 | t, agent, draw index) (cz_spawn_uniform is the host mirror), so results depend neither on the batch size
+ * nor on the sharding nor on the launch form.  Per agent the record's status word carries a "despawned" bit and a 5-bit
+ * grace countdown from bit 8 + 6 * agent.  A despawned agent does not act (as with action -1), is reported truncated in the
+ * step it leaves, and stays in the world as an obstacle; an agent that holds something stays.  Takes effect with the next
+ * cz_reset / auto-reset (fresh worlds start with everybody present and the grace period running); rates 0, 0 switch it
+ * off.  spawn_x / spawn_y: [num_agents][32] candidate coordinates (the level file's AGENTS entries), n_x / n_y how many. */
+int cz_set_spawn(cz_handle h, double despawn_rate, double respawn_rate, int32_t grace_period, uint64_t seed,
+                 const uint8_t *spawn_x, const int32_t *n_x, const uint8_t *spawn_y, const int32_t *n_y);
+double cz_spawn_uniform(uint64_t seed, int64_t env_global, uint32_t episode, uint32_t t, int32_t agent, uint32_t draw);
+
 /* ---- state ----------------------------------------------------------------------------------------- */
 int cz_set_state(cz_handle h, int64_t env_begin, int64_t env_count, const uint32_t *records);
 int cz_get_state(cz_handle h, int64_t env_begin, int64_t env_count, uint32_t *records);

@@ -1,0 +1,175 @@
+"""Agent despawn / respawn evaluated by the step kernels (cz_set_spawn, Ops::handle_agent_spawn) against the host model
+(cooking_zoo_amd/spawn.py SpawnBook, and the scalar transliteration of the reference's rule in test_spawn_book.py) on top of
+the oracle: every stepping path - cz_step, cz_step_device, overlapped ring runs, cz_rollout - and shard invariance."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cooking_zoo_amd import soa
+from cooking_zoo_amd.spawn import SpawnBook, status_bits
+
+pytestmark = pytest.mark.gpu
+KW = dict(action_scheme="scheme3", num_layouts=6, auto_reset=True, agent_despawn_rate=0.15, agent_respawn_rate=0.25, grace_period=2, spawn_seed=5)
+RECIPES = ["TomatoSalad", "TomatoLettuceSalad", "no_recipe", "MashedCarrotBanana"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+def make(n, base=0, max_steps=40, **kw):
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    k = dict(KW)
+    k.update(kw)
+    return CookingVecEnv(n, "crowded_6x5", "crowded_6x5", 4, max_steps, RECIPES, env_id_base=base, **k)
+
+
+class Model:
+    """oracle world step + the host model of handle_agent_spawn (vectorised SpawnBook, or the scalar rule)"""
+
+    def __init__(self, env, scalar=False):
+        from oracle_binding import VecOracle
+        self.env, self.orc, self.scalar = env, VecOracle.from_vec_env(env), scalar
+        d, r, g, seed = env._spawn_cfg
+        self.book = SpawnBook(env.num_envs, env.num_agents, env.spawn_cells, despawn_rate=d, respawn_rate=r, grace_period=g,
+                              seed=seed, env_id_base=env.env_id_base)
+
+    def reset(self):
+        self.book.reset_all()
+        return self.orc.reset()
+
+    def records(self):
+        r = self.orc.records.copy()
+        r[:, soa.W_STATUS] |= status_bits(self.book.active, self.book.grace)
+        return r
+
+    def step(self, acts):
+        orc, book, dims = self.orc, self.book, self.env.dims
+        done_before = (orc.records[:, soa.W_STATUS] & 1).astype(bool)
+        obs, rew, term, trunc = orc.step(book.mask_actions(acts))
+        book.reset_envs(done_before)                       # auto-reset pass: a fresh world, everybody present
+        if self.scalar:
+            moved = self._scalar_after_step(~done_before)
+        else:
+            moved = book.after_step(orc.records, dims, stepped=~done_before)
+        for e in moved:
+            obs[e] = orc.oracle.observe(orc.records[e])
+        trunc = trunc | (book.changed & ~book.active).astype(np.uint8)
+        return obs, rew, term, trunc
+
+    def _scalar_after_step(self, stepped):
+        from test_spawn_book import scalar_rule
+        book, recs, dims = self.book, self.orc.records, self.env.dims
+        book._key = (recs[:, soa.W_EPISODE].astype(np.uint64) << np.uint64(32)) | recs[:, soa.W_T].astype(np.uint64)
+        moved = []
+        for e in np.nonzero(stepped)[0]:
+            st = dict(active=book.active[e].tolist(), changed=book.changed[e].tolist(), grace=book.grace[e].tolist(), seed=book.seed,
+                      despawn=book.despawn_rate, respawn=book.respawn_rate, grace_period=book.grace_period)
+            before_active = list(st["active"])
+            scalar_rule(st, recs[e], dims, int(book.env_ids[e]), int(book._key[e]))
+            for i in range(book.A):                            # respawn_agent: the new location (parsing.py:154-167)
+                if st["active"][i] and not before_active[i]:
+                    x, y = book._generate_location(recs[e], dims, i, int(e))
+                    _, _, o, h = soa.unpack_agent(recs[e, soa.AGENT_WORD0 + i])
+                    recs[e, soa.AGENT_WORD0 + i] = soa.pack_agent(x, y, o, h)
+                    moved.append(int(e))
+            book.active[e], book.changed[e], book.grace[e] = st["active"], st["changed"], st["grace"]
+        return sorted(set(moved))
+
+
+def strip(recs):
+    r = recs.copy()
+    r[:, soa.RET_WORD0:soa.RET_WORD0 + 8] = 0
+    return r
+
+
+def test_host_array_step_and_device_step_match_the_model():
+    n, A = 48, 4
+    env, twin = make(n), make(n)
+    mdl = Model(env)
+    og = env.reset()
+    twin.reset(return_obs=False)
+    assert np.array_equal(bits(og), bits(mdl.reset()))
+    assert np.array_equal(strip(env.get_state()), mdl.records())
+    d_act = twin.alloc((n, A), np.int32)
+    d_obs, d_rew = twin.alloc((n, A, twin.F), np.float64), twin.alloc((n, A), np.float64)
+    d_t, d_u = twin.alloc((n, A), np.uint8), twin.alloc((n, A), np.uint8)
+    rng = np.random.default_rng(1)
+    n_gone = n_back = 0
+    for t in range(150):
+        acts = rng.integers(0, 5, size=(n, A), dtype=np.int32)
+        og, rg, tg, ug = env.step(acts)
+        om, rm, tm, um = mdl.step(acts)
+        assert np.array_equal(bits(og), bits(om)), f"observation at step {t}"
+        assert np.array_equal(bits(rg), bits(rm)) and np.array_equal(tg, tm), f"rewards / terminations at step {t}"
+        assert np.array_equal(ug, um), f"truncations at step {t}"
+        assert np.array_equal(strip(env.get_state()), mdl.records()), f"records at step {t}"
+        assert np.array_equal(env.spawn.active, mdl.book.active) and np.array_equal(env.spawn.grace, mdl.book.grace)
+        n_gone += int((mdl.book.changed & ~mdl.book.active).sum())
+        n_back += int((mdl.book.changed & mdl.book.active).sum())
+        # the device-pointer path does the same
+        d_act.from_host(acts)
+        twin.step_device(d_act, d_obs, d_rew, d_t, d_u)
+        twin.sync()
+        assert np.array_equal(bits(d_obs.to_host()), bits(om)) and np.array_equal(d_u.to_host(), um)
+    assert np.array_equal(strip(twin.get_state()), mdl.records())
+    assert n_gone > 100 and n_back > 100
+    env.close()
+    twin.close()
+
+
+def test_rollout_matches_the_scalar_rule_and_is_shard_invariant():
+    """cz_rollout with on-device actions: 48 worlds against the scalar transliteration of the reference's rule fed with the same
+    keyed draws; the same 48 worlds as six handles of 8 (global env ids) end in the same records."""
+    from cooking_zoo_amd import _native
+    n, A, T, seed = 48, 4, 40, 77
+    env = make(n)
+    parts = [make(8, base=8 * k) for k in range(6)]
+    mdl = Model(env, scalar=True)
+    env.reset(return_obs=False)
+    [p.reset(return_obs=False) for p in parts]
+    mdl.reset()
+    L = _native.lib()
+    d_obs, d_rew = env.alloc((T, n, A, env.F), np.float64), env.alloc((T, n, A), np.float64)
+    d_t, d_u = env.alloc((T, n, A), np.uint8), env.alloc((T, n, A), np.uint8)
+    for chunk in range(3):
+        step0 = chunk * T
+        env.rollout(T, seed, step0, d_obs, d_rew, d_t, d_u)
+        [p.rollout(T, seed, step0) for p in parts]
+        env.sync()
+        obs, rew, term, trunc = d_obs.to_host(), d_rew.to_host(), d_t.to_host(), d_u.to_host()
+        for t in range(T):
+            acts = np.array([[L.cz_action(seed, e, a, step0 + t, env.n_actions) for a in range(A)] for e in range(n)], dtype=np.int32)
+            om, rm, tm, um = mdl.step(acts)
+            assert np.array_equal(bits(obs[t]), bits(om)), (chunk, t)
+            assert np.array_equal(bits(rew[t]), bits(rm)) and np.array_equal(term[t], tm) and np.array_equal(trunc[t], um), (chunk, t)
+        assert np.array_equal(strip(env.get_state()), mdl.records()), chunk
+        whole = strip(env.get_state())
+        split = np.concatenate([strip(p.get_state()) for p in parts])
+        assert np.array_equal(whole, split), f"sharded records after chunk {chunk}"
+    active = mdl.book.active
+    assert (~active).sum() > 5 and active.any(axis=1).all()
+    env.close()
+    [p.close() for p in parts]
+
+
+def test_overlapped_ring_runs_do_the_same_bookkeeping():
+    n, A, period, K = 256, 4, 16, 48
+    env, ref = make(n, max_steps=25), make(n, max_steps=25)
+    env.set_overlap(True)
+    env.reset(return_obs=False)
+    ref.reset(return_obs=False)
+    rng = np.random.default_rng(3)
+    ring_host = rng.integers(0, 5, size=(period, n, A), dtype=np.int32)
+    d_ring = env.alloc((period, n, A), np.int32)
+    d_ring.from_host(ring_host)
+    outs = [env.alloc((n, A, env.F), np.float64), env.alloc((n, A), np.float64), env.alloc((n, A), np.uint8), env.alloc((n, A), np.uint8)]
+    env.step_device_ring(K, d_ring, n * A, period, 0, *outs)
+    env.sync()
+    for k in range(K):
+        o, r, t, u = ref.step(ring_host[k % period])
+    assert np.array_equal(strip(env.get_state()), strip(ref.get_state()))
+    assert np.array_equal(bits(outs[0].to_host()), bits(o)) and np.array_equal(outs[3].to_host(), u)
+    env.close()
+    ref.close()

@@ -51,10 +51,12 @@ def test_vectorised_bookkeeping_equals_the_scalar_rule():
             for a in range(A):
                 x, y, o, _ = soa.unpack_agent(recs[e, soa.AGENT_WORD0 + a])
                 recs[e, soa.AGENT_WORD0 + a] = soa.pack_agent(x, y, o, 0 if rng.random() < 0.2 else -1)
+        recs[:, soa.W_T] = t                                                # (the draws are keyed by each world's episode and step counter)
+        recs[:, soa.W_EPISODE] = np.arange(N) % 3
         before = recs.copy()
         moved = set(book.after_step(recs, dims).tolist())
         for e in range(N):
-            m = scalar_rule(twins[e], before[e], dims, 1000 + e, t)
+            m = scalar_rule(twins[e], before[e], dims, 1000 + e, ((e % 3) << 32) | t)
             assert book.active[e].tolist() == twins[e]["active"], (t, e)
             assert book.changed[e].tolist() == twins[e]["changed"], (t, e)
             assert book.grace[e].tolist() == twins[e]["grace"], (t, e)
