@@ -151,8 +151,9 @@ enum : uint32_t { LC_GROUPS = 0, LC_ACTIVE = 1 };
 // The reference draws from numpy's process-global stream, which defines the draws of ONE world per process; a batch takes every
 // draw from a counter-based stream keyed by (seed, global env id, episode << 32 | t, agent, draw index) instead - the same
 // function as cooking_zoo_amd/spawn.py `uniform` - so results depend neither on the batch size nor on the sharding nor on how
-// the steps are launched (one per launch, overlapped, fused).  Per agent the record's status word carries, from bit 8 + 6 a:
-// 1 bit "despawned" and 5 bits of grace countdown.  The parameters live in device memory behind the quotient table.
+// the steps are launched (one per launch, overlapped, fused).  The record's status word carries one "despawned" bit per agent
+// (bit 8 + a) and five bits of grace countdown each (from bit 12 + 5 a).  The parameters live in device memory behind the
+// quotient table.
 struct SpawnCfg {
     uint64_t seed;
     double despawn_rate, respawn_rate;
@@ -160,10 +161,11 @@ struct SpawnCfg {
     struct Area { uint8_t nx, ny, pad[2]; uint8_t xs[32], ys[32]; } area[MAX_AGENTS];      // the level file's spawn areas (parsing.py:118-151)
 };
 constexpr uint32_t SPAWN_CFG_OFFSET = 256 * 8 + 64 * 4;      // bytes behind Params::lut: the 256 doubles and the 64 submask words
-constexpr int SPAWN_SHIFT0 = 8, SPAWN_BITS = 6, SPAWN_MAX_GRACE = 31;
+// status word: bit 8 + a = agent a is despawned; bits 12 + 5 a .. 16 + 5 a = its grace countdown
+constexpr int SPAWN_GONE0 = 8, SPAWN_GRACE0 = 12, SPAWN_GRACE_BITS = 5, SPAWN_MAX_GRACE = 31;
 __host__ __device__ inline uint32_t spawn_initial_status(uint32_t grace_period, int n_agents) {   // everybody present, grace running
     uint32_t st = 0;
-    for (int a = 0; a < n_agents; ++a) st |= grace_period << (SPAWN_SHIFT0 + SPAWN_BITS * a + 1);
+    for (int a = 0; a < n_agents; ++a) st |= grace_period << (SPAWN_GRACE0 + SPAWN_GRACE_BITS * a);
     return st;
 }
 __host__ __device__ inline uint64_t spawn_mix(uint64_t x) {                      // splitmix64 finaliser
@@ -566,11 +568,13 @@ struct Ops {
     // pre-pass, both filters and all walking: after this the agents' positions and orientations are final for the step
     static __device__ __forceinline__ Pre agents_walk(E &e, const Ctx &cx, uint32_t act_raw, Dirty &dt) {
         const uint32_t W = (uint32_t)cx.W, H = (uint32_t)cx.H;
+        // (despawned agents, cz_set_spawn: bits 8.. of the status word, all 0 in batches without despawn / respawn)
+        const uint64_t present_m = ~(uint64_t)((e.status >> SPAWN_GONE0) & 0xFu);
         const uint32_t agw = e.agw;                                        // 0 on lanes >= NA
         const uint32_t x = agw & 0xFFu, y = (agw >> 8) & 0xFFu, xy = agw & 0xFFFFu;
         // a negative action = the agent is despawned: it is not in the list world_step acts on (cooking_world.py:105-108:
         // no turn, no move, no part in the collision filter) but keeps its place in the world
-        const uint64_t agent_m = ballot((int32_t)act_raw >= 0) & ((1ull << NA) - 1ull);
+        const uint64_t agent_m = ballot((int32_t)act_raw >= 0) & ((1ull << NA) - 1ull) & present_m;
         const uint32_t act0 = lanes(agent_m) ? (act_raw & 7u) : 0u;        // (lanes >= NA carry a copy of the last agent's action)
         const uint32_t sh = 2u * act0;
         const uint32_t tx = x + ((DX_TABLE >> sh) & 3u) - 1u, ty = y + ((DY_TABLE >> sh) & 3u) - 1u;   // negative wraps to huge
@@ -701,26 +705,23 @@ struct Ops {
         const uint64_t seed = cfg->seed, key = ((uint64_t)e.episode << 32) | (uint64_t)e.t;
         const double despawn_rate = cfg->despawn_rate, respawn_rate = cfg->respawn_rate;
         uint32_t st = e.status, gone = 0u;
-        uint32_t gone_bits = 0u;
-#pragma unroll
-        for (int a = 0; a < NA; ++a) gone_bits |= 1u << (SPAWN_SHIFT0 + SPAWN_BITS * a);
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            const int sh = SPAWN_SHIFT0 + SPAWN_BITS * a;
-            if ((st >> (sh + 1)) & 31u) { st -= 1u << (sh + 1); continue; }          // agent_grace_period[i] -= 1
-            const bool despawned = (st >> sh) & 1u;
+            const int gsh = SPAWN_GRACE0 + SPAWN_GRACE_BITS * a;
+            if ((st >> gsh) & 31u) { st -= 1u << gsh; continue; }                    // agent_grace_period[i] -= 1
+            const bool despawned = (st >> (SPAWN_GONE0 + a)) & 1u;
             if (!despawned) {
-                const int n_active = NA - __popc(st & gone_bits);
+                const int n_active = NA - __popc((st >> SPAWN_GONE0) & 0xFu);
                 if (n_active > 1 && spawn_uniform(seed, (uint64_t)env_global, key, (uint32_t)a, 0u) < despawn_rate) {
                     if ((rdl(e.agw, a) >> 24) == 0u) {                                // despawn_agent: an agent that holds something stays
-                        st |= 1u << sh;
+                        st |= 1u << (SPAWN_GONE0 + a);
                         gone |= 1u << a;
                     }
                 }
             } else if (spawn_uniform(seed, (uint64_t)env_global, key, (uint32_t)a, 1u) < respawn_rate) {
                 // respawn_agent: back, grace period restarted, on a Floor cell of its spawn area that nobody - active or
                 // not, itself included - stands on (generate_location: up to 1001 tries)
-                st = (st & ~(63u << sh)) | (cfg->grace_period << (sh + 1));
+                st = (st & ~(1u << (SPAWN_GONE0 + a))) | (cfg->grace_period << gsh);
                 const uint32_t nx = cfg->area[a].nx, ny = cfg->area[a].ny;
 #pragma nounroll
                 for (uint32_t k = 0; k < 1001u; ++k) {

@@ -410,8 +410,8 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
     }
     o.stepped = true;
     e.t += 1;                                                        // cooking_env.py:244
-    // a despawned agent is not in the list world_step acts on (cooking_world.py:105-108): action -1
-    if (spawning) acts = (cx.lane < NA && ((e.status >> (SPAWN_SHIFT0 + SPAWN_BITS * cx.lane)) & 1u)) ? 0xFFFFFFFFu : acts;
+    // (a despawned agent is not in the list world_step acts on, cooking_world.py:105-108: agents_walk takes it out like an
+    // agent with action -1)
 #if defined(CZ_PROFILE)
     const int lane = cx.lane; const long long env = env_global - P.env_id_base;
 #endif
@@ -708,7 +708,12 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
                 // (write-through in an overlapped run: the next launch rewrites the same bytes, possibly from another XCD)
                 if (!FUSED || rewards) strec<double>(chained, rewards, oidx * 8u, myrew);
                 if (!FUSED || term) strec<uint8_t>(chained, term, oidx, (uint8_t)o.term);
-                if (!FUSED || trunc) strec<uint8_t>(chained, trunc, oidx, (uint8_t)(o.trunc | ((o.gone >> lane) & 1u)));
+                if (!FUSED || trunc) {
+                    strec<uint8_t>(chained, trunc, oidx, (uint8_t)o.trunc);
+                    // whoever was despawned in this step is reported truncated once (cooking_env.py:344-349): a second store by
+                    // those lanes, on the rare steps on which somebody leaves
+                    if (o.gone && ((o.gone >> lane) & 1u)) strec<uint8_t>(chained, trunc, oidx, (uint8_t)1);
+                }
             }
         }
         if (!FUSED) {

@@ -123,16 +123,17 @@ class SpawnBook:
         return self.active | self.changed
 
 
-# ---- the device's encoding of this bookkeeping in record word W_STATUS (csrc/cz_device.h SPAWN_*): from bit 8 + 6 a one
-# "despawned" bit and five bits of grace countdown per agent
-SPAWN_SHIFT0, SPAWN_BITS, SPAWN_MAX_GRACE = 8, 6, 31
+# ---- the device's encoding of this bookkeeping in record word W_STATUS (csrc/cz_device.h SPAWN_*): bit 8 + a = agent a is
+# despawned, bits 12 + 5 a .. 16 + 5 a = its grace countdown
+SPAWN_GONE0, SPAWN_GRACE0, SPAWN_GRACE_BITS, SPAWN_MAX_GRACE = 8, 12, 5, 31
 
 
 def status_bits(active, grace):
     """[N, A] bool active, [N, A] int grace -> uint32 [N] to be or-ed into the status word"""
     out = np.zeros(active.shape[0], dtype=np.uint32)
     for a in range(active.shape[1]):
-        out |= ((~active[:, a]).astype(np.uint32) | (grace[:, a].astype(np.uint32) << np.uint32(1))) << np.uint32(SPAWN_SHIFT0 + SPAWN_BITS * a)
+        out |= (~active[:, a]).astype(np.uint32) << np.uint32(SPAWN_GONE0 + a)
+        out |= grace[:, a].astype(np.uint32) << np.uint32(SPAWN_GRACE0 + SPAWN_GRACE_BITS * a)
     return out
 
 
@@ -142,7 +143,6 @@ def decode_status(status, num_agents):
     active = np.empty((status.shape[0], num_agents), dtype=bool)
     grace = np.empty((status.shape[0], num_agents), dtype=np.int64)
     for a in range(num_agents):
-        f = (status >> np.uint32(SPAWN_SHIFT0 + SPAWN_BITS * a)) & np.uint32(63)
-        active[:, a] = (f & 1) == 0
-        grace[:, a] = f >> 1
+        active[:, a] = ((status >> np.uint32(SPAWN_GONE0 + a)) & np.uint32(1)) == 0
+        grace[:, a] = (status >> np.uint32(SPAWN_GRACE0 + SPAWN_GRACE_BITS * a)) & np.uint32(31)
     return active, grace

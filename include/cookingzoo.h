@@ -121,8 +121,8 @@ int64_t cz_layout_updates(cz_handle h);
  * cz_step_device*, overlapped runs, cz_rollout.  The reference takes its draws from numpy's process-global stream, which
  * defines them for one world per process; here every draw comes from a counter-based stream keyed by (seed, global env id,
  * episode << 32 | t, agent, draw index) (cz_spawn_uniform is the host mirror), so results depend neither on the batch size
- * nor on the sharding nor on the launch form.  Per agent the record's status word carries a "despawned" bit and a 5-bit
- * grace countdown from bit 8 + 6 * agent.  A despawned agent does not act (as with action -1), is reported truncated in the
+ * nor on the sharding nor on the launch form.  The record's status word carries a "despawned" bit per agent (bit 8 + agent)
+ * and a 5-bit grace countdown each (from bit 12 + 5 * agent).  A despawned agent does not act (as with action -1), is reported truncated in the
  * step it leaves, and stays in the world as an obstacle; an agent that holds something stays.  Takes effect with the next
  * cz_reset / auto-reset (fresh worlds start with everybody present and the grace period running); rates 0, 0 switch it
  * off.  spawn_x / spawn_y: [num_agents][32] candidate coordinates (the level file's AGENTS entries), n_x / n_y how many. */
