@@ -120,6 +120,174 @@ def pmc_traffic(kernel_key):
     return best
 
 
+def roofline_block(b_alg, units, us_per_launch, kernel, note=None):
+    """algorithmic bytes per env-step x env-steps per launch / launch duration, against the 8 TB/s HBM peak"""
+    achieved = b_alg * units / (us_per_launch * 1e-6) / 1e9
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+           "kernel": kernel, "kernel_us": us_per_launch, "alg_bytes_per_env_step": b_alg, "units_per_launch": units}
+    if note:
+        out["kernel_us_from"] = note
+    return out
+
+
+def timed_ring(env, K, ring, outs, reps=3):
+    """K boundary-ordered launches (graph replay) timed with HIP events on the handle's stream, best of `reps`; -> us per launch"""
+    from cooking_zoo_amd import _native
+    L, h = _native.lib(), env._h
+    d_ring, stride, period = ring
+    _native.check(h, L.cz_ring_prepare(h, K, d_ring, stride, period, 0, *outs))
+    _native.check(h, L.cz_step_device_ring(h, min(K, period), d_ring, stride, period, 0, *outs))       # warm
+    best = None
+    ms = C.c_float()
+    for _ in range(reps):
+        _native.check(h, L.cz_timer_start(h))
+        _native.check(h, L.cz_step_device_ring(h, K, d_ring, stride, period, 0, *outs))
+        _native.check(h, L.cz_timer_stop(h, C.byref(ms)))
+        best = ms.value if best is None else min(best, ms.value)
+    return best * 1e3 / K
+
+
+def leg_closed_loop(env, d_obs, d_rew, d_term, d_trunc):
+    """What a reinforcement-learning loop gets: cz_step_device, then a kernel of the caller that turns the observation into the
+    next actions, then the next step - every step waits for a policy that waits for the step before it.  (The policy here is
+    the cheapest possible one; a real one adds its own time.)"""
+    from cooking_zoo_amd import _native
+    L, h = _native.lib(), env._h
+    N, A = env.num_envs, env.num_agents
+    d_act = env.alloc((N, A), np.int32)
+    d_act.from_host(np.random.default_rng(7).integers(0, env.n_actions, size=(N, A), dtype=np.int32))
+    K, reps = 200, 10
+    us = C.c_float()
+    s0 = env.stats()["env_steps"]
+    _native.check(h, L.cz_probe_closed_loop(h, K, reps, d_act.ptr, d_obs.ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr, C.byref(us)))
+    stepped = (env.stats()["env_steps"] - s0) / float(N * K * (reps + 1))        # (auto-reset passes are not env steps)
+    d_act.free()
+    b_alg = algorithmic_bytes_per_env_step(env)
+    return {"env_steps_per_s": stepped * N / (us.value * 1e-6), "us_per_step": us.value, "envs": N,
+            "what": "closed loop on one stream: cz_step_device -> policy kernel (next actions = hash of the observation just written) "
+                    f"-> cz_step_device ...; {K}-step HIP graph replayed {reps} times, HIP events; includes the policy kernel and its launch boundary",
+            "roofline": roofline_block(b_alg, N, us.value, "cz::k_step<1,1,2,3,false> + k_probe_policy per step",
+                                       "HIP events around graph replays of the closed loop; step + policy kernel + both boundaries")}
+
+
+def leg_cooking_policy(device_id):
+    """The one-step kernel under a policy that cooks: the reference's heuristic agent's action sequences (golden fixtures
+    cfg2_coop_2agents, episodes that end with a delivered dish), every env on one of those worlds at its own phase of the
+    episode; when an episode ends the env resets onto a world of the same pool and follows that world's sequence."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import golden_io                                                    # (fixture loader: data, not the oracle)
+    from cooking_zoo_amd import _native, soa
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    gs = golden_io.GoldenSet("cfg2_coop_2agents")
+    eps = [ep for ep in gs.episodes if ep.policy in ("heuristic", "mixed") and ep.terms.any()]
+    lays = [golden_io.layout_from_episode(ep) for ep in eps]
+    N, A, P = 4096, 2, len(eps)
+    env = CookingVecEnv(N, gs.cfg["level"], gs.cfg["meta_file"], A, gs.cfg["max_steps"], list(gs.cfg["recipes"]),
+                        action_scheme="scheme3" if gs.scheme == 3 else "scheme1", layouts=lays, auto_reset=True, device_id=device_id)
+    L, h = _native.lib(), env._h
+    env.reset(return_obs=False)
+    T = [len(ep.actions) for ep in eps]
+    # env e: world j = the layout it drew for episode 0, phase s_e of that world's episode
+    recs = env.get_state()
+    rng = np.random.default_rng(3)
+    lay0 = recs[:, soa.W_LAYOUT].astype(int)
+    phase = np.array([rng.integers(0, T[j]) for j in lay0])
+    hdr = [soa.W_LAYOUT, soa.W_RECIPES, soa.W_POOL, soa.W_EPISODE]
+    for e in range(N):
+        keep = recs[e, hdr].copy()
+        recs[e] = eps[lay0[e]].states[phase[e]]
+        recs[e, hdr] = keep
+        recs[e, soa.W_STATUS] = 0
+    env.set_state(recs)
+    # the action ring: follow each env through its episodes (termination -> one auto-reset pass -> next world from phase 0)
+    K = 512
+    ring = np.zeros((K, N, A), dtype=np.int32)
+    pool_word = int(recs[0, soa.W_POOL])
+    for e in range(N):
+        j, s, ep_no, k = int(lay0[e]), int(phase[e]), 0, 0
+        while k < K:
+            n = min(T[j] - s, K - k)
+            ring[k:k + n, e] = eps[j].actions[s:s + n]
+            k += n
+            if k < K:
+                k += 1                                                   # the auto-reset pass (its action is ignored)
+                ep_no += 1
+                j, s = int(L.cz_next_layout(env.env_id_base + e, ep_no, pool_word, P)), 0
+    d_ring = env.alloc((K, N, A), np.int32)
+    d_ring.from_host(ring)
+    d_obs, d_rew = env.alloc((N, A, env.F), np.float64), env.alloc((N, A), np.float64)
+    d_t, d_u = env.alloc((N, A), np.uint8), env.alloc((N, A), np.uint8)
+    outs = (d_obs.ptr, d_rew.ptr, d_t.ptr, d_u.ptr)
+    env.reset_stats()
+    s0 = env.stats()
+    ms = C.c_float()
+    _native.check(h, L.cz_ring_prepare(h, K, d_ring.ptr, N * A, K, 0, *outs))
+    _native.check(h, L.cz_timer_start(h))
+    _native.check(h, L.cz_step_device_ring(h, K, d_ring.ptr, N * A, K, 0, *outs))
+    _native.check(h, L.cz_timer_stop(h, C.byref(ms)))
+    st = env.stats()
+    us = ms.value * 1e3 / K
+    b_alg = algorithmic_bytes_per_env_step(env)
+    out = {"env_steps_per_s": (st["env_steps"] - s0["env_steps"]) / (ms.value * 1e-3), "us_per_launch": us, "envs": N, "launches": K,
+           "episodes_terminated_by_a_delivered_dish": st["terminations"] - s0["terminations"], "episodes_truncated": st["truncations"] - s0["truncations"],
+           "return_sum_agent0": st["return_sum"][0],
+           "what": f"one launch per step, launch-boundary ordering (graph replay); every env replays the reference heuristic agent's actions "
+                   f"(golden fixtures cfg2_coop_2agents: {P} episodes of {min(T)}-{max(T)} steps that chop, plate and deliver) from its own phase",
+           "roofline": roofline_block(b_alg, N, us, "cz::k_step<1,1,2,3,false>", "HIP events around one graph-replayed run of 512 launches")}
+    env.close()
+    return out
+
+
+def leg_configs(device_id, which=("config3", "config5", "config4_shard")):
+    """BASELINE configs 3 and 5 and one rank's shard of config 4: one launch per step (graph replay) and fused (cz_rollout), a few
+    hundred milliseconds each."""
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    out = {}
+    for name in which:
+        if name == "config3":
+            n = 65536
+            rid = np.array([[e % 8, (e + 1) % 8] for e in range(n)])
+            env = CookingVecEnv(n, ["coop_test", "coexistence_test", "switch_test"], "example", 2, 400, rid, action_scheme="scheme3",
+                                num_layouts=256, device_id=device_id)
+            what, K, T = "65536 envs, levels e % 3 of coop / coexistence / switch, recipes cycling over the book, 2 agents", 60, 16
+        elif name == "config5":
+            env = CookingVecEnv(65536, "large_16x16", "large_16x16", 4, 400, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"],
+                                action_scheme="scheme3", num_layouts=64, device_id=device_id)
+            what, K, T = "65536 envs, 4 agents, large_16x16 at maximum object density, F = %d" % env.F, 24, 4
+        else:
+            env = CookingVecEnv(32768, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3",
+                                num_layouts=256, env_id_base=98304, device_id=device_id)
+            what, K, T = "one rank's shard of config 4: 32768 of 262144 envs (global ids from 98304), coop_test, 2 agents", 100, 16
+        N, A = env.num_envs, env.num_agents
+        env.reset(return_obs=False)
+        period = 16
+        d_ring = env.alloc((period, N, A), np.int32)
+        d_ring.from_host(np.random.default_rng(5).integers(0, env.n_actions, size=(period, N, A), dtype=np.int32))
+        d_obs, d_rew = env.alloc((N, A, env.F), np.float64), env.alloc((N, A), np.float64)
+        d_t, d_u = env.alloc((N, A), np.uint8), env.alloc((N, A), np.uint8)
+        us = timed_ring(env, K, (d_ring.ptr, N * A, period), (d_obs.ptr, d_rew.ptr, d_t.ptr, d_u.ptr))
+        # fused: T steps per launch, trajectory buffer
+        d_traj = env.alloc((T, N, A, env.F), np.float64)
+        env.rollout(T, 1, 0, d_traj)
+        env.sync()
+        reps = max(2, K // T)
+        t0 = time.perf_counter()
+        for r in range(reps):
+            env.rollout(T, 1, (r + 1) * T, d_traj)
+        env.sync()
+        us_fused = (time.perf_counter() - t0) * 1e6 / (reps * T)
+        b_alg = algorithmic_bytes_per_env_step(env)
+        stepping = 400.0 / 401.0                                        # one launch in 401 is an env's auto-reset pass
+        kern = "cz::k_step (instance %s)" % ("1 slot / 1 cell per lane" if env.dims.D <= 64 and env.dims.C <= 64 else "2 slots / 4 cells per lane")
+        out[name] = {"workload": what, "envs": N, "agents": A, "F": env.F,
+                     "per_step": {"env_steps_per_s": stepping * N / (us * 1e-6), "us_per_launch": us,
+                                  "roofline": roofline_block(b_alg, N, us, kern, "HIP events around graph replays of %d launches, best of 3" % K)},
+                     "fused": {"env_steps_per_s": stepping * N / (us_fused * 1e-6), "us_per_step": us_fused, "steps_per_launch": T,
+                               "roofline": roofline_block(b_alg, N, us_fused, kern + ", fused", "wall clock around %d cz_rollout launches of %d steps" % (reps, T))}}
+        env.close()
+    return out
+
+
 def with_deadline(fn, seconds):
     """fn() on a helper thread; -> (finished, result or exception)."""
     box = {}
@@ -143,6 +311,8 @@ def parse_args(argv=None):
     ap.add_argument("--repeats", type=int, default=30, help="how many times the K-step region is timed (median reported)")
     ap.add_argument("--envs", type=int, default=4096, help="env instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline measurement: skip closed_loop / cooking_policy / configs / config4 (profiling runs)")
     ap.add_argument("--no-obs", action="store_true", help="ablation only: skip the observation encode (INVALID as a result)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work at all: every rank reports made-up timings so that the launcher / rendezvous / "
@@ -351,6 +521,35 @@ def worker_body(args, rdzv, overlap, note):
     mine = {"elapsed_s": elapsed, "env_steps": steps_done, "kernel_us": kernel_us, "stats": env.stats()}
     every = [json.loads(b) for b in rdzv.all_gather(json.dumps(mine).encode())]
 
+    # ---- BASELINE config 4 when there are several ranks: 262144 envs over 8 GPUs = 32768 envs per rank, global env ids (the
+    # statistics exchange below is that config's only collective); every rank times the same K-step regions between barriers
+    cfg4_every = None
+    if world > 1 and not args.no_extras:
+        n4, K4, R4 = 32768, 100, 5
+        env4 = CookingVecEnv(n4, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3",
+                             num_layouts=256, layout_seed=0, auto_reset=True, device_id=local_rank, env_id_base=rank * n4)
+        env4.reset(return_obs=False)
+        d_ring4 = env4.alloc((16, n4, 2), np.int32)
+        d_ring4.from_host(np.random.default_rng(99 + rank).integers(0, 5, size=(16, n4, 2), dtype=np.int32))
+        o4 = (env4.alloc((n4, 2, env4.F), np.float64).ptr, env4.alloc((n4, 2), np.float64).ptr, env4.alloc((n4, 2), np.uint8).ptr,
+              env4.alloc((n4, 2), np.uint8).ptr)
+        h4 = env4._h
+        _native.check(h4, L.cz_ring_prepare(h4, K4, d_ring4.ptr, n4 * 2, 16, 0, *o4))
+        _native.check(h4, L.cz_step_device_ring(h4, 16, d_ring4.ptr, n4 * 2, 16, 0, *o4))
+        el4, st4 = [], []
+        for r in range(R4):
+            s0 = env4.stats()["env_steps"]
+            env4.sync(); barrier()
+            t0 = time.perf_counter()
+            _native.check(h4, L.cz_step_device_ring(h4, K4, d_ring4.ptr, n4 * 2, 16, 0, *o4))
+            env4.sync()
+            el4.append(time.perf_counter() - t0)
+            barrier()
+            st4.append(env4.stats()["env_steps"] - s0)
+        cfg4_every = [json.loads(b) for b in rdzv.all_gather(json.dumps({"elapsed_s": el4, "env_steps": st4, "kernel_us": [0.0] * R4}).encode())]
+        b_alg4 = algorithmic_bytes_per_env_step(env4)
+        env4.close()
+
     # ---- episode statistics: RCCL all-gather over xGMI of one cz_stats per rank (the path's only collective), checked
     # against the same structs exchanged over the control plane
     stats_all = {}
@@ -424,10 +623,10 @@ def worker_body(args, rdzv, overlap, note):
             "repeats": agg["repeats"], "value_min": agg["value_min"], "value_max": agg["value_max"],
             "ms_per_step_min": agg["ms_per_step_min"], "ms_per_step_max": agg["ms_per_step_max"],
             "timing": "median over `repeats` K-step regions, each bracketed by stream sync + all-rank barrier, MAX over ranks per region",
-            "config": {"workload": f"{N} envs per GPU x {world} GPU(s), level=coop_test, 2 agents, "
-                                   f"recipes=[TomatoLettuceSalad, CarrotBanana], scheme3, max_steps=400, "
-                                   f"256-layout pool, on-device auto-reset, feature_vector obs F={env.F} f64, "
-                                   f"uniform random actions",
+            "config": {"workload": f"{N} envs/GPU x {world} GPU, coop_test, 2 agents, [TomatoLettuceSalad, CarrotBanana], scheme3, "
+                                   f"max_steps=400, f64 obs F={env.F}",
+                       "details": "256-layout pool, on-device next-step auto-reset, feature_vector observation encoded every step, uniform random "
+                                  "actions resident in HBM, device-resident outputs",
                        "envs_per_gpu": N, "parallelism": f"env-sharded x{world}, one wavefront per env, one process per GPU, no torch",
                        "api": api},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -457,6 +656,19 @@ def worker_body(args, rdzv, overlap, note):
             line["overlap_fallback"] = note
         if fused is not None:
             line["fused_rollout"] = fused
+            fused["roofline"] = roofline_block(b_alg, N, fused["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,true> (32 steps per launch)",
+                                               "wall clock around the cz_rollout launches")
+        if cfg4_every is not None:
+            a4 = aggregate(cfg4_every, 100)
+            line["config4"] = {"workload": f"BASELINE config 4 shape: 32768 envs per GPU x {world} GPU(s) = {32768 * world} envs, coop_test, 2 agents, global env ids, "
+                                           f"statistics all-gather over RCCL; one launch per step (graph replay), 100-step regions between all-rank barriers",
+                               "value": a4["value"], "unit": "env-steps/s", "ms_per_step": a4["ms_per_step"], "value_min": a4["value_min"], "value_max": a4["value_max"],
+                               "roofline": roofline_block(b_alg4, 32768, a4["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,false>", "wall clock of the slowest rank per region")}
+        if world == 1 and not args.no_extras and not args.no_obs:
+            # what users get beside the open-loop headline; each leg a fraction of a second of GPU time
+            line["closed_loop"] = leg_closed_loop(env, d_obs, d_rew, d_term, d_trunc)
+            line["cooking_policy"] = leg_cooking_policy(local_rank)
+            line["configs"] = leg_configs(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(env)
         emit(line)

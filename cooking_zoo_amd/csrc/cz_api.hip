@@ -110,6 +110,18 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_probe_occupy(unsigned long
     if (sink) sink[0] = hold[threadIdx.x];          // never true: keeps the allocation alive
 }
 
+// measurement aid (cz_probe_closed_loop): the smallest "policy" there is - every agent's next action is a hash of a few
+// doubles of the observation it was just given - so that step k + 1 depends on step k's observation through a kernel of the
+// caller, as in any reinforcement-learning loop
+__global__ void k_probe_policy(const double *__restrict__ obs, int32_t *__restrict__ actions, int n_rows, int F, uint32_t n_actions) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;               // (env, agent)
+    if (row >= n_rows) return;
+    const unsigned long long *o = reinterpret_cast<const unsigned long long *>(obs) + (size_t)row * F;
+    unsigned long long x = o[0] ^ (o[F / 3] * 3ull) ^ (o[(2 * F) / 3] * 5ull) ^ (o[F - 1] * 7ull) ^ ((unsigned long long)row << 17);
+    x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33;
+    actions[row] = (int32_t)(((x & 0xFFFFFFFFull) * n_actions) >> 32);
+}
+
 // cz_load_layouts with a smaller pool: how many resident records still point past the new pool (layout id or redraw slice)
 __global__ void k_layout_misfits(const uint32_t *__restrict__ state, int RW, int N, uint32_t n_new, unsigned long long *count) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1310,6 +1322,48 @@ extern "C" int cz_probe_output_only(cz_handle h, void *d_dst, size_t bytes, int3
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *us_per_launch = ms * 1e3f / (float)reps;
+    return 0;
+}
+
+// Measurement aid for bench.py: a CLOSED loop of K steps - cz_step_device, then a policy kernel that derives every agent's
+// next action from the observation it has just been given, on the same stream - captured into one HIP graph and replayed
+// `reps` times; returns the average time per step (step + policy).  d_actions (int32 [N][A]) is read and rewritten in place.
+extern "C" int cz_probe_closed_loop(cz_handle h, int32_t K, int32_t reps, int32_t *d_actions, double *d_obs, double *d_rewards,
+                                    uint8_t *d_term, uint8_t *d_trunc, float *us_per_step) {
+    if (ready(h)) return 1;
+    if (K < 1 || K > 1024 || reps < 1 || !d_actions || !d_obs || !us_per_step) return fail(h, "cz_probe_closed_loop: bad arguments");
+    if (set_device(h)) return 1;
+    Params P = h->P;
+    P.actions = d_actions; P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
+    const int rows = h->P.N * h->P.A;
+    const uint32_t n_actions = h->P.scheme == 3 ? 5u : 8u;
+    const bool was_timing = h->ktime;
+    h->ktime = false;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int bad = 0;
+    for (int k = 0; k < K && !bad; ++k) {
+        bad = launch_step(h, P);
+        if (!bad) hipLaunchKernelGGL(k_probe_policy, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, d_obs, d_actions, rows, h->P.F, n_actions);
+    }
+    const hipError_t ec = hipStreamEndCapture(h->stream, &g);
+    h->ktime = was_timing;
+    if (bad) { if (g) (void)hipGraphDestroy(g); return 1; }
+    HIPCHK(h, ec);
+    const hipError_t ei = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIPCHK(h, ei);
+    hipError_t rc = hipGraphLaunch(ge, h->stream);                         // warm
+    if (rc == hipSuccess) rc = hipEventRecord(h->ev0, h->stream);
+    for (int r = 0; r < reps && rc == hipSuccess; ++r) rc = hipGraphLaunch(ge, h->stream);
+    if (rc == hipSuccess) rc = hipEventRecord(h->ev1, h->stream);
+    if (rc == hipSuccess) rc = hipEventSynchronize(h->ev1);
+    float ms = 0.f;
+    if (rc == hipSuccess) rc = hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    (void)hipGraphExecDestroy(ge);
+    HIPCHK(h, rc);
+    *us_per_step = ms * 1e3f / (float)((int64_t)reps * K);
     return 0;
 }
 

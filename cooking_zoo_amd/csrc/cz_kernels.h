@@ -756,8 +756,13 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
 #endif
 }
 
+#ifdef CZ_STEP_WPE            // experiment: occupancy target of the ordinary kernels
+#define CZ_STEP_ATTR __attribute__((amdgpu_waves_per_eu(CZ_STEP_WPE, CZ_STEP_WPE)))
+#else
+#define CZ_STEP_ATTR
+#endif
 template <int OPL, int CPL, int NA, int SCHEME, bool FUSED>
-__global__ __launch_bounds__(64 * envs_per_wg<CPL>()) void k_step(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
+__global__ __launch_bounds__(64 * envs_per_wg<CPL>()) CZ_STEP_ATTR void k_step(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
                                                           int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
                                                           int32_t e_dyn1, const Params P0) {
     step_kernel<OPL, CPL, NA, SCHEME, FUSED, false>(e_state, e_actions, e_lut, e_N, e_RW, e_W, e_H, e_D, e_dyn0, e_dyn1, 0u, P0);

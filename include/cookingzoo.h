@@ -247,6 +247,11 @@ int cz_kernel_time_read(cz_handle h, double *total_ms, int64_t *launches);
  * nothing but write `bytes` (<= 2 GiB) to d_dst with the encode's 16-byte write-through stores -- the floor of a launch
  * that has to emit that much output (bench.py reports it next to the roofline).  d_dst is overwritten. */
 int cz_probe_output_only(cz_handle h, void *d_dst, size_t bytes, int32_t reps, float *us_per_launch);
+/* measurement aid: a CLOSED loop - K times (cz_step_device, then a tiny policy kernel that derives every agent's next action
+ * from the observation it was just given, same stream), one HIP graph, replayed `reps` times; average microseconds per
+ * step (step + policy).  d_actions (int32 [N][A]) is read and rewritten in place; K <= 1024. */
+int cz_probe_closed_loop(cz_handle h, int32_t K, int32_t reps, int32_t *d_actions, double *d_obs, double *d_rewards,
+                         uint8_t *d_terminations, uint8_t *d_truncations, float *us_per_step);
 /* test aid: `workgroups` workgroups of a foreign kernel (512 threads and 34 KB of LDS each, like the step kernel's) hold
  * their slots for `microseconds` on a stream of their own; returns at once.  Stands in for a caller's own long-running
  * kernels next to an overlapped run. */
