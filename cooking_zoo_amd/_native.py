@@ -107,15 +107,39 @@ class _LateTorchGuard:
     this library links.  Loaded after this library, they sit next to the system copies already in use: everything seems
     to work until the process aborts in a destructor at exit ("double free or corruption", rc 134).  The working order is
     torch first (both then share torch's runtime), so a first `import torch` that comes too late is refused with an
-    explanation instead.  CZ_ALLOW_LATE_TORCH=1 removes the guard."""
+    explanation - at the moment torch's module is EXECUTED, not when somebody merely asks whether torch is installed
+    (`importlib.util.find_spec("torch")` keeps returning a spec), and only for a torch that really bundles a HIP runtime of
+    its own (a CPU-only build, or one built against the system ROCm, imports as usual).  Installed as a side effect of
+    loading the library; CZ_ALLOW_LATE_TORCH=1 removes the guard."""
+
+    MESSAGE = ("`import torch` after cooking_zoo_amd has loaded libcookingzoo_hip.so: torch's bundled ROCm runtime would be loaded next "
+               "to the system one already in use and the process would abort at exit. Import torch BEFORE creating the first "
+               "cooking_zoo_amd environment (see INTEGRATION.md), or set CZ_ALLOW_LATE_TORCH=1 to take the risk.")
+
+    class _Refuse:
+        def __init__(self, inner):
+            self._inner = inner
+
+        def create_module(self, spec):
+            return None
+
+        def exec_module(self, module):
+            raise ImportError(_LateTorchGuard.MESSAGE)
 
     def find_spec(self, name, path=None, target=None):
-        if name == "torch":
-            raise ImportError("`import torch` after cooking_zoo_amd has loaded libcookingzoo_hip.so: torch's bundled ROCm runtime "
-                              "would be loaded next to the system one already in use and the process would abort at exit. Import "
-                              "torch BEFORE creating the first cooking_zoo_amd environment (see INTEGRATION.md), or set "
-                              "CZ_ALLOW_LATE_TORCH=1 to take the risk.")
-        return None
+        if name != "torch":
+            return None
+        import glob
+        import importlib.machinery
+        spec = importlib.machinery.PathFinder.find_spec(name, path)
+        if spec is None or not spec.submodule_search_locations:
+            return None                                   # not installed: the ordinary "No module named torch"
+        bundled = any(glob.glob(os.path.join(loc, "lib", pat)) for loc in spec.submodule_search_locations
+                      for pat in ("libamdhip64.so*", "librccl.so*"))
+        if not bundled:
+            return None                                   # no runtime of its own: nothing to collide with
+        spec.loader = self._Refuse(spec.loader)
+        return spec
 
 
 def lib():

@@ -154,3 +154,28 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_binding" not in text and "libcz_oracle" not in text and "czo_" not in text.replace("czo_action", ""), f
+
+
+def test_late_torch_guard_refuses_the_load_not_the_probe(tmp_path):
+    """cooking_zoo_amd._native installs an import hook once the HIP library is loaded: a torch that bundles a ROCm runtime of
+    its own must not be EXECUTED afterwards - but asking whether torch is installed keeps working, and a torch without a
+    bundled runtime (or any other module) is left alone."""
+    import importlib.machinery
+    import sys
+    from cooking_zoo_amd import _native
+    g = _native._LateTorchGuard()
+    assert g.find_spec("numpy") is None and g.find_spec("torch.nn") is None
+    fake = tmp_path / "site"
+    (fake / "torch" / "lib").mkdir(parents=True)
+    (fake / "torch" / "__init__.py").write_text("x = 1\n")
+    sys.path.insert(0, str(fake))
+    try:
+        assert g.find_spec("torch") is None                          # no runtime of its own: nothing to collide with
+        (fake / "torch" / "lib" / "libamdhip64.so.7").write_bytes(b"")
+        importlib.invalidate_caches()
+        spec = g.find_spec("torch")
+        assert spec is not None and spec.origin.endswith("__init__.py")     # availability probes get a spec
+        with pytest.raises(ImportError, match="Import torch BEFORE"):
+            spec.loader.exec_module(None)
+    finally:
+        sys.path.remove(str(fake))

@@ -7,8 +7,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-cur}
 O=gpurun_out/prof_$TAG
-TRACE_ARGS=${TRACE_ARGS:---steps 400 --warmup 40 --repeats 5}
-PMC_ARGS="--steps 40 --warmup 10 --repeats 3"
+TRACE_ARGS=${TRACE_ARGS:---steps 400 --warmup 40 --repeats 5 --no-extras}
+PMC_ARGS="--steps 40 --warmup 10 --repeats 3 --no-extras"
 mkdir -p $O/trace $O/fetch $O/write $O/insts
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py $TRACE_ARGS --no-cpu-baseline > $O/bench_under_trace.json 2> $O/trace.log
 echo "trace rc=$?"
