@@ -655,9 +655,18 @@ struct Ops {
         // evaluated in step_env), the quick majority fills in behind them.
         if (inter & (inter - 1)) CZ_SETPRIO(2);
         else if (inter) CZ_SETPRIO(1);
+#ifndef CZ_INTER_UNROLL
+#define CZ_INTER_UNROLL 0
+#endif
+#if CZ_INTER_UNROLL
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            if (!((inter >> a) & 1ull)) continue;
+#else
         while (inter) {
             const int a = __builtin_ctzll(inter);
             inter &= inter - 1;
+#endif
             const uint32_t A = rdl(e.agw, a);
             Me me{A & 0xFFFFu, (int)(A >> 24) - 1};
             // the cell in front (scheme3: the bumped cell; scheme1: by orientation, may be off-grid)
