@@ -320,6 +320,11 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     if (cfg->action_scheme != 1 && cfg->action_scheme != 3)
         return fail(nullptr, "cz_create: action_scheme must be 1 or 3 (scheme2 is unusable in the reference)");
     if (cfg->max_steps < 1 || cfg->feat_len < 1) return fail(nullptr, "cz_create: max_steps and feat_len must be positive");
+    {   // the kernels address a handle's records and one-step outputs with 32-bit offsets
+        const uint64_t rw = ((uint64_t)(20 + (C + 3) / 4 + 2 * cfg->max_dyn) + 15) / 16 * 16;
+        if ((uint64_t)cfg->num_envs * rw * 4 >= (1ull << 32) || (uint64_t)cfg->num_envs * cfg->num_agents * 8 >= (1ull << 32))
+            return fail(nullptr, "cz_create: num_envs too large for one handle (records must stay below 4 GiB): use several handles");
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, "cz_create: no HIP device available (this library has no CPU fallback)");
@@ -430,8 +435,23 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
         }
         // ... followed by the despawn / respawn parameters (SpawnCfg, cz_set_spawn; all zero: switched off)
         static_assert(SPAWN_CFG_OFFSET == sizeof lut + sizeof submask, "layout of the block behind Params::lut");
-        CREATE_CHK(hipMalloc(&h->d_lut, sizeof lut + sizeof submask + sizeof(SpawnCfg)));
-        CREATE_CHK(hipMemset(h->d_lut, 0, sizeof lut + sizeof submask + sizeof(SpawnCfg)));
+        // ... the image words of the cells' coordinates (init_lds: x + W - 1 and 63 + y + H - 1 as byte offsets into this table,
+        // one word per cell) and, per lane, which word of which of the env's recipe rows it holds (load_recipe_rows)
+        uint32_t coords[1024], rowsel[64];
+        const uint32_t c01 = (uint32_t)((P.W - 1) * 8) | ((uint32_t)((LUT_Y0 + P.H - 1) * 8) << 16);
+        for (uint32_t c = 0; c < 1024; ++c) {
+            const uint32_t y = c / (uint32_t)P.W, x = c - y * (uint32_t)P.W;
+            coords[c] = (y < 64u) ? ((x << 3) | (y << 19)) + c01 : 0u;
+        }
+        for (uint32_t l = 0; l < 64; ++l) {
+            const uint32_t lc = l < 9u * (uint32_t)P.R ? l : 9u * (uint32_t)P.R - 1u;       // lanes past the rows repeat the last word
+            rowsel[l] = (8u * (lc / 9u)) | ((4u * (lc % 9u)) << 8);
+        }
+        static_assert(LUT_BLOCK_BYTES == sizeof lut + sizeof submask + sizeof(SpawnCfg) + sizeof coords + sizeof rowsel, "layout of the block behind Params::lut");
+        CREATE_CHK(hipMalloc(&h->d_lut, LUT_BLOCK_BYTES));
+        CREATE_CHK(hipMemset(h->d_lut, 0, LUT_BLOCK_BYTES));
+        CREATE_CHK(hipMemcpy((char *)h->d_lut + COORD_TABLE_OFFSET, coords, sizeof coords, hipMemcpyHostToDevice));
+        CREATE_CHK(hipMemcpy((char *)h->d_lut + ROWSEL_TABLE_OFFSET, rowsel, sizeof rowsel, hipMemcpyHostToDevice));
         CREATE_CHK(hipMemcpy(h->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
         CREATE_CHK(hipMemcpy((char *)h->d_lut + sizeof lut, submask, sizeof submask, hipMemcpyHostToDevice));
         P.lut = h->d_lut;

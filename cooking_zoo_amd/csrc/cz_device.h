@@ -160,7 +160,12 @@ struct SpawnCfg {
     uint32_t grace_period, pad;
     struct Area { uint8_t nx, ny, pad[2]; uint8_t xs[32], ys[32]; } area[MAX_AGENTS];      // the level file's spawn areas (parsing.py:118-151)
 };
+static_assert(sizeof(SpawnCfg) == 32 + 4 * 68, "layout of the block behind Params::lut");
 constexpr uint32_t SPAWN_CFG_OFFSET = 256 * 8 + 64 * 4;      // bytes behind Params::lut: the 256 doubles and the 64 submask words
+// ... then two more per-lane constant tables (cz_create): the cell-coordinate image words of cells 0..1023, and for lane l
+// which word of which recipe row it holds (load_recipe_rows): 8 r | 4 i << 8 for word i of the env's r-th recipe
+constexpr uint32_t COORD_TABLE_OFFSET = SPAWN_CFG_OFFSET + 32 + 4 * 68, ROWSEL_TABLE_OFFSET = COORD_TABLE_OFFSET + 1024 * 4;
+constexpr uint32_t LUT_BLOCK_BYTES = ROWSEL_TABLE_OFFSET + 64 * 4;
 // status word: bit 8 + a = agent a is despawned; bits 12 + 5 a .. 16 + 5 a = its grace countdown
 constexpr int SPAWN_GONE0 = 8, SPAWN_GRACE0 = 12, SPAWN_GRACE_BITS = 5, SPAWN_MAX_GRACE = 31;
 __host__ __device__ inline uint32_t spawn_initial_status(uint32_t grace_period, int n_agents) {   // everybody present, grace running

@@ -190,12 +190,12 @@ __device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL, N
     }
 }
 
-// the recipe rows of this env, one word per lane: lane 9r + i = word i of the row of recipe r
+// the recipe rows of this env, one word per lane: lane 9r + i = word i of the row of recipe r (which r, i a lane stands for is
+// a constant of the lane, made by the host: 8 r | 4 i << 8; lanes past the rows repeat the last word)
 __device__ __forceinline__ uint32_t load_recipe_rows(const Params &P, uint32_t recipes, int lane) {
-    const uint32_t l = min((uint32_t)lane, 9u * (uint32_t)P.R - 1u);          // lanes past the rows re-read the last word
-    const uint32_t r = __umul24(l, 57u) >> 9, i = l - __umul24(r, 9u);        // l / 9 for l < 64
-    const uint32_t id = (recipes >> (8u * r)) & 0xFFu;
-    return ldg<uint32_t>(P.recipes, (__umul24(id, 1u + MAX_NODES) + i) * 4u);
+    const uint32_t sel = ldg<uint32_t>(P.lut, ROWSEL_TABLE_OFFSET + (uint32_t)lane * 4u);
+    const uint32_t id = (recipes >> (sel & 0xFFu)) & 0xFFu;
+    return ldg<uint32_t>(P.recipes, __umul24(id, (1u + MAX_NODES) * 4u) + (sel >> 8));
 }
 
 // every recipe of the env from scratch (reset): sets e.marks (and e.marks_hi for wide tables)
@@ -224,32 +224,30 @@ __device__ __forceinline__ void init_lut(const Params &P, double *lut, int tid, 
     for (int i = tid; i < LUT_SIZE; i += nthreads) lut[i] = ldg<double>(P.lut, (uint32_t)i * 8u);
 }
 
-// once per kernel and env: the constant part of the image (cell coordinates)
+// once per kernel and env: the constant part of the image (cell coordinates: a host-made table, one word per cell)
 template <int CPL>
 __device__ __forceinline__ void init_lds(const Params &P, const Ctx &cx, Lds<CPL> &s) {
     const int lane = cx.lane;
     s.img[Img<CPL>::ZERO] = (uint16_t)(LUT_ABSENT * 8);           // (every lane, same value: cheaper than switching lanes off)
     uint32_t *img32 = reinterpret_cast<uint32_t *>(s.img);
-    const uint32_t c01 = (uint32_t)((P.W - 1) * 8) | ((uint32_t)((LUT_Y0 + P.H - 1) * 8) << 16);
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
-        uint32_t c = (uint32_t)(lane + 64 * k);
-        uint32_t y = __umul24(c, P.inv_w) >> 16;             // exact for c < 1024 (checked on the host); full-rate 24-bit multiplies
-        uint32_t x = c - __umul24(y, (uint32_t)P.W);
-        img32[(Img<CPL>::CELL0 >> 1) + 2 * c] = ((x << 3) | (y << 19)) + c01;
+        const uint32_t c = (uint32_t)(lane + 64 * k);
+        img32[(Img<CPL>::CELL0 >> 1) + 2 * c] = ldg<uint32_t>(P.lut, COORD_TABLE_OFFSET + c * 4u);
     }
 }
 
 // the descriptor words of this lane for one chunk: pair i of a chunk covers features [(chunk*OBS_PAIRS + i)*128 + 2*lane, +1].
-// Buffer loads over a resource that ends with the layout's F descriptors: words past F read as 0 (hardware range check,
-// dword by dword), so there are no clamps, no masks and no branches on F.
+// Buffer loads over one resource that spans the whole descriptor table (the layout's row is the scalar offset): no clamps, no
+// masks, no branches on F.  Words past the row's F descriptors are the next layout's - valid image offsets like any other,
+// read for nothing since the stores of features past F are out of their row's range - or, behind the table's end, 0.
 __device__ __forceinline__ void load_desc(const Params &P, uint32_t layout, int chunk, int lane, uint32_t (&dsc)[OBS_CHUNK]) {
-    const uint32_t *__restrict__ desc = P.lay_desc + (size_t)layout * (uint32_t)P.F;      // uniform base
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(desc), 0, P.F * 4, 0x00020000);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(P.lay_desc), 0, P.L * P.F * 4, 0x00020000);
+    const uint32_t row = layout * (uint32_t)P.F * 4u;                                       // uniform
 #pragma unroll
     for (int i = 0; i < OBS_CHUNK / 2; ++i) {
         const uint32_t f = (uint32_t)(chunk * (OBS_CHUNK / 2) + i) * 128u + 2u * (uint32_t)lane;
-        const uint2_t d = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, f * 4u, 0, 0));
+        const uint2_t d = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, f * 4u, row, 0));
         dsc[2 * i] = d.x; dsc[2 * i + 1] = d.y;
     }
 }
@@ -575,7 +573,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     Lds<CPL> &lds = lds_all[wave];
     Ctx cx{P.W, P.H, P.D, P.W * P.H, lane};
     CZ_STAMP(0);
-    uint32_t *rec = P.state + (size_t)env * P.RW;
+    uint32_t *rec = P.state + (uint32_t)env * (uint32_t)P.RW;        // (cz_create: the records of a handle stay below 4 GiB)
     double *retp = reinterpret_cast<double *>(rec + RET_WORD0);
     // ---- an overlapped launch first waits for its env's predecessor (SEQ_* in cz_device.h); ordinary launches skip this
     uint32_t *const seqw = P.state + (size_t)P.N * P.RW + (size_t)env * SEQ_STRIDE_WORDS;
@@ -587,7 +585,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         // What does not depend on the predecessor happens before the wait: the actions, the constant part of the LDS image
         // and the workgroup's table with its barrier.  With the barrier in front of the wait the eight envs of a workgroup
         // stay independent - behind it, every one of them would start only when the slowest of the eight predecessors is done.
-        av = ldg<int>(P.actions + (size_t)env * NA, (uint32_t)min(lane, NA - 1) * 4u);
+        av = ldg<int>(P.actions, ((uint32_t)env * (uint32_t)NA + (uint32_t)min(lane, NA - 1)) * 4u);
         init_lds<CPL>(P, cx, lds);
         if (threadIdx.x < (unsigned)LUT_SIZE) lut[threadIdx.x] = lutv;
         __syncthreads();
@@ -627,7 +625,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     // agent-scope one would invalidate the L2 on every poll - but the compiler must not move the loads up:)
     if (CHAIN) asm volatile("" ::: "memory");
     // ---- every load of the step is issued here, before anything waits
-    if (!FUSED && !CHAIN) av = ldg<int>(P.actions + (size_t)env * NA, (uint32_t)min(lane, NA - 1) * 4u);
+    if (!FUSED && !CHAIN) av = ldg<int>(P.actions, ((uint32_t)env * (uint32_t)NA + (uint32_t)min(lane, NA - 1)) * 4u);
     double ret = ldrec<double>(chained, retp, ((uint32_t)lane & 3u) * 8u);                                       // running episode return, lane a = agent a
     Env<OPL, CPL, NA> e;
     load_env(P, e, cx, rec, chained);
@@ -724,7 +722,8 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         img_objs |= (dt.touched | dt.moved) != 0;
         img_cells |= dt.cells != 0;
         if (Pt.obs) {
-            observe(Pt, e, cx, lds, lut, dsc, submask, Pt.obs + row * (size_t)NA * Pt.F, img_objs, img_cells);
+            // (env row x row length: a 32 x 32 -> 64-bit product, two scalar multiplies)
+            observe(Pt, e, cx, lds, lut, dsc, submask, Pt.obs + (uint64_t)(uint32_t)row * (uint64_t)(uint32_t)(NA * Pt.F), img_objs, img_cells);
             img_objs = false; img_cells = false;
         }
         CZ_STAMP(6);
