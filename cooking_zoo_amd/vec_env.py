@@ -275,14 +275,16 @@ class CookingVecEnv:
         self._lay_groups, self._lay_active = int(groups), int(active)
         self.rotation_events.append((self._steps, "group", int(groups), int(active)))
 
-    def rotate_layouts(self, every, *, groups=2, seed=0, prefetch=2):
+    def rotate_layouts(self, every, *, groups=2, seed=0, prefetch=2, blocking=True):
         """Keep the layout pool fresh while the batch steps - the batched counterpart of the reference instantiating a new
         level at every reset (cooking_env.py:191-195, parsing.py:21-151).  The pool slices are cut into `groups` parts; the
         envs draw from one; every `every` steps (at the next call boundary) the next part becomes the one drawn from, and
         once the episodes that started on the old part are over (max_steps + 2 steps later) it is refilled with layouts
         a background process has instantiated meanwhile (engine/load_level.py, its own seeded stream per refill).  Which
         layouts an env sees is a function of the sequence of stepping calls only (the refill waits for that process if it
-        has to), so a run can be replayed: `rotation_events` lists what was switched / replaced at which step."""
+        has to), so a run can be replayed: `rotation_events` lists what was switched / replaced at which step.
+        `blocking=False` never waits: a refill whose layouts are not ready yet is tried again at the next call boundary (and
+        the next switch with it), which keeps the stepping thread free of stalls at the price of a timing-dependent schedule."""
         if self._rot is not None:
             raise RuntimeError("rotate_layouts is already running")
         if groups < 2 or any(count % groups for _, count in self.pool_slices):
@@ -290,7 +292,8 @@ class CookingVecEnv:
         if every < self.max_steps + 3:
             raise ValueError("`every` must be at least max_steps + 3 steps: a part is refilled max_steps + 2 steps after the "
                              "envs stopped drawing from it, and before they draw from it again")
-        rot = {"groups": int(groups), "every": int(every), "flip_due": self._steps + int(every), "refill_due": None, "n_refills": 0}
+        rot = {"groups": int(groups), "every": int(every), "flip_due": self._steps + int(every), "refill_due": None, "n_refills": 0,
+               "blocking": bool(blocking)}
 
         # The instantiation is plain Python (engine/load_level.py, the reference's draw order) and takes milliseconds per batch:
         # in a thread it would hold the interpreter lock against the thread that issues the steps, so it runs in a process of
@@ -350,7 +353,11 @@ class CookingVecEnv:
         if rot is None:
             return
         if rot["refill_due"] is not None and self._steps >= rot["refill_due"]:
-            for first, lays, recs, desc in rot["ready"].get():              # (waits for the producer if it is behind)
+            try:
+                batch = rot["ready"].get(block=rot["blocking"])            # (blocking: waits for the producer if it is behind)
+            except _queue.Empty:
+                return                                                      # not ready: next call
+            for first, lays, recs, desc in batch:
                 self._update_layout_arrays(first, lays, recs, desc)
             rot["refill_due"] = None
             rot["n_refills"] += 1
