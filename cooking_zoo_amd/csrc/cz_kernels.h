@@ -769,8 +769,9 @@ __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) CZ_STEP_ATTR void k_step(u
 // Overlapped launches exist for the small instance only (one slot and one cell per lane: every shipped level): that is where
 // the gain was measured (4096 envs of the 7x7 levels), and the only instance that meets the eight-waves target below
 // without spilling vector registers - the 2 / 4 instance spilled 9-37 VGPRs to scratch under it, the 4 / 16 instance cannot
-// meet it at all.  Batches of the larger instances are bound by their observation writes and replay graphs.
-template <int OPL, int CPL> constexpr bool chain_instance() { return OPL == 1 && CPL == 1; }
+// meet it at all - and there for up to three agents: with four the kernel needs 65 vector registers, one more than eight
+// waves per SIMD leave.  Batches of the larger instances are bound by their observation writes and replay graphs.
+template <int OPL, int CPL, int NA> constexpr bool chain_instance() { return OPL == 1 && CPL == 1 && NA <= 3; }
 // (one more leading scalar: the launch's sequence word; it fills the padding in front of P0, whose offset stays the same)
 // Eight waves per SIMD (<= 96 SGPRs, at the price of ~45 spilled ones): four workgroups per CU, so that two of these
 // kernels are resident IN FULL at the batch sizes that may overlap.  With the 106 SGPRs the compiler takes by itself only
@@ -858,7 +859,7 @@ struct Inst {
         constexpr int EPW = envs_per_wg<CPL>();
         int per_cu = 0;
         hipError_t e = hipSuccess;
-        if constexpr (chain_instance<OPL, CPL>()) {
+        if constexpr (chain_instance<OPL, CPL, NA>()) {
             if (P.scheme == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step_chain<OPL, CPL, NA, 3>, 64 * EPW, 0);
             else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step_chain<OPL, CPL, NA, 1>, 64 * EPW, 0);
         }
@@ -883,7 +884,7 @@ struct Inst {
 #define CZ_LAUNCH_CHAIN(S) \
     hipLaunchKernelGGL((k_step_chain<OPL, CPL, NA, S>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, E.seq, P)
         if (P.actions && (P.seq & SEQ_PUBLISH)) {
-            if constexpr (chain_instance<OPL, CPL>()) {
+            if constexpr (chain_instance<OPL, CPL, NA>()) {
                 if (P.scheme == 3) CZ_LAUNCH_CHAIN(3);
                 else CZ_LAUNCH_CHAIN(1);
             } else {
