@@ -103,13 +103,14 @@ int cz_load_layouts(cz_handle h, const uint32_t *init_records, const uint32_t *o
 /* Fresh layouts under a stepping batch (the reference draws a new level at every reset, cooking_env.py:191-195,
  * parsing.py:21-151; the device redraws from the resident pool).  cz_update_layouts replaces pool slots
  * [first, first + count) - same formats as cz_load_layouts - without touching the handle's stream: the tables stay where they
- * are, the caller's arrays are free again on return, and the copy runs on a stream of the library's own, ordered after
- * every step issued so far and not waited for by later steps.  Never replace slots that envs can still draw or are still
+ * are, the caller's arrays are free again on return, and the copy runs on a stream of the library's own, issued once every
+ * step issued before the call has completed (checked at later call boundaries, never a device-side wait) and not waited for
+ * by later steps.  Never replace slots that envs can still draw or are still
  * playing on: cz_set_layout_group(h, groups, active) cuts every env's pool slice into `groups` equal parts and lets the envs
  * draw their next episodes from part `active` only (1, 0 = the whole slice, the default), from the next step on (stream
  * order); it waits - on the device - for the updates issued so far, so no env draws a half-written slot.  Rotation:
  * switch to part b; issue at least max_steps + 1 more steps (every episode that started on part a has ended); update
- * part a; ... (cooking_zoo_amd.vec_env.CookingVecEnv.rotate_layouts does this from a background thread).  Every pool slice's
+ * part a; ... (cooking_zoo_amd.vec_env.CookingVecEnv.rotate_layouts does this with a background process).  Every pool slice's
  * length must be a multiple of `groups`.  cz_update_layouts with count 0 only creates the copy stream and the staging block
  * (so that the first real update does not pay for them).  cz_layout_updates: slots replaced so far. */
 int cz_update_layouts(cz_handle h, int32_t first, int32_t count, const uint32_t *init_records, const uint32_t *obs_desc);
