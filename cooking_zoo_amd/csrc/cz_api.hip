@@ -866,8 +866,13 @@ static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr) {
     if (chain_failed(h, "step launch")) return 1;
     if (!stream) stream = h->stream;
     // write-through observation stores pay when the launch is short enough for the end-of-kernel L2 write-back to be
-    // exposed: one step of a moderate batch.  (CZ_WT=0/1 overrides, for experiments.)
-    P.wt = (P.actions != nullptr && (size_t)P.N * P.A * P.F * 8 <= ((size_t)128 << 20)) ? 1 : 0;
+    // exposed: one step of a moderate batch; streaming stores when one launch's observations do not fit the memory-side
+    // cache (256 MiB) any more.  (CZ_WT=0/1/2 overrides, for experiments.)
+    const size_t obs_bytes = (size_t)P.N * P.A * P.F * 8;
+    if (P.actions) P.wt = obs_bytes <= ((size_t)128 << 20) ? 1 : obs_bytes > ((size_t)224 << 20) ? 2 : 0;
+    // (fused: streaming stores only when an agent's row fills whole DRAM pages - 4 KiB and more, config 5: +8 %; with the
+    // 2.2 KB rows of the 7x7 levels they lose 15 % against the cache's own write-back order, profiles/r03/wt_ab2.txt)
+    else P.wt = (obs_bytes > ((size_t)224 << 20) && (size_t)P.F * 8 >= 4096) ? 2 : 0;
     if (h->wt_override >= 0) P.wt = h->wt_override;
     if (P.actions) {          // the one-step kernels store rewards and flags unconditionally
         if (!P.rewards) P.rewards = (double *)h->d_dump;

@@ -253,11 +253,15 @@ __device__ __forceinline__ void load_desc(const Params &P, uint32_t layout, int 
 }
 
 // cooking_env.py:352-373 get_feature_vector for every agent of the env: out[a][f] = lut[img[desc.hw] - sub[a][desc.code]]
-// P.wt = write-through stores (`buffer_store_dwordx4 ... sc1`): the observation bytes leave the XCD's L2 while the kernel
-// still computes instead of staying dirty until the end-of-kernel write-back (which serialises ~B / 6 TB/s behind every
-// launch: MI355X_MICROARCH.md "boundary" / "publish-large").  Pays for one launch per step; the fused kernel, whose
-// launch boundary is amortised over T steps, and large batches, whose stores drain while other waves still compute,
-// keep plain stores (policy in cz_api.hip launch_step).
+// P.wt selects the cache policy of the observation stores (wave-uniform; policy in cz_api.hip launch_step):
+//   1 = write-through (`buffer_store_dwordx4 ... sc1`): the bytes leave the XCD's L2 while the kernel still computes instead
+//       of staying dirty until the end-of-kernel write-back (which serialises ~B / 6 TB/s behind every launch:
+//       MI355X_MICROARCH.md "boundary" / "publish-large").  Pays for one launch per step of a moderate batch.
+//   2 = streaming (`... nt`): for output buffers larger than the memory-side cache.  With plain stores a launch's 278+ MiB of
+//       observations sweep the 256 MiB Infinity Cache, so the records, tables and descriptors the NEXT waves read come
+//       from HBM, queued behind the writes: a one-step launch of 65 536 envs takes 80 us with plain stores and 56 us with
+//       streaming ones (profiles/r03/aux_sweep.txt).
+//   0 = plain: the fused kernel (its launch boundary is amortised over T steps) and batches in between.
 template <int OPL, int CPL, int NA>
 __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, Lds<CPL> &s,
                                         const double *lut, uint32_t (&dsc)[OBS_CHUNK], uint32_t submask, double *__restrict__ out /* [A][F] of this env */,
@@ -318,7 +322,7 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
     decltype(__builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0)) rs[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) rs[a] = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)a * (uint32_t)P.F, 0, P.F * 8, 0x00020000);
-    const bool wt = P.wt != 0;                                                          // wave-uniform
+    const uint32_t wt = (uint32_t)P.wt;                                                 // wave-uniform
     const char *lutb = reinterpret_cast<const char *>(lut);
     const char *imgb = reinterpret_cast<const char *>(s.img);
     const char *subb = reinterpret_cast<const char *>(s.sub);
@@ -343,19 +347,14 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
                 v[a][i].y = *reinterpret_cast<const double *>(lutb + ((int)b[2 * i + 1] - sb[a][2 * i + 1]));
             }
         const uint32_t f0b = (uint32_t)(chunk * OBS_PAIRS * 128 + 2 * cx.lane) * 8u;      // byte offset of this lane's first pair
-        if (wt) {
-#pragma unroll
-            for (int i = 0; i < OBS_PAIRS; ++i)
-#pragma unroll
-                for (int a = 0; a < NA; ++a)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v[a][i]), rs[a], f0b + (uint32_t)i * 1024u, 0, 16);
-        } else {
-#pragma unroll
-            for (int i = 0; i < OBS_PAIRS; ++i)
-#pragma unroll
-                for (int a = 0; a < NA; ++a)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v[a][i]), rs[a], f0b + (uint32_t)i * 1024u, 0, 0);
-        }
+#define CZ_OBS_STORES(AUX)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < OBS_PAIRS; ++i)                                                                    \
+        _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                                       \
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v[a][i]), rs[a], f0b + (uint32_t)i * 1024u, 0, AUX)
+        if (wt == 1u) { CZ_OBS_STORES(16); }            // sc1: write-through
+        else if (wt == 2u) { CZ_OBS_STORES(2); }        // nt: streaming
+        else { CZ_OBS_STORES(0); }
+#undef CZ_OBS_STORES
     }
     // the caller keeps the descriptors of chunk 0 across steps (fused rollout): restore them if later chunks replaced them
     if (P.F > 128 * OBS_PAIRS) load_desc(P, e.layout, 0, cx.lane, dsc);
@@ -755,8 +754,12 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
 #endif
 }
 
-#ifdef CZ_STEP_WPE            // experiment: occupancy target of the ordinary kernels
-#define CZ_STEP_ATTR __attribute__((amdgpu_waves_per_eu(CZ_STEP_WPE, CZ_STEP_WPE)))
+// (experiment switch: occupancy target of the one-step kernels of the small and the middle instance.  All of them reach six
+// waves per SIMD by themselves except the middle instance with four agents - config 5's kernel: 82 vector registers, four
+// waves - and forcing that one to six (80 registers, 3 spilled) changed nothing: 195 against 197 M env-steps/s,
+// profiles/r03/wpe_ab.txt)
+#ifdef CZ_STEP_MIN_WPE
+#define CZ_STEP_ATTR __attribute__((amdgpu_waves_per_eu((!FUSED && OPL <= 2) ? CZ_STEP_MIN_WPE : 1)))
 #else
 #define CZ_STEP_ATTR
 #endif

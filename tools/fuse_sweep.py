@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""cz_rollout at a large batch with T = 1, 2, 4, 8, 16 steps per launch: how much of the fused kernel's advantage comes from
+"""cz_rollout with T = 1, 2, 4, 8, 16 steps per launch (python3 tools/fuse_sweep.py [N [T,T,.. [steps [noobs]]]]): how much of the fused kernel's advantage comes from
 amortising the launch (end-of-kernel write-back, cold start, ramp)?"""
 import ctypes as C, os, sys, time
 import numpy as np
@@ -11,10 +11,12 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 env = CookingVecEnv(N, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3", num_layouts=256)
 h = env._h
 env.reset(return_obs=False)
-Tmax = 16
-d_traj = env.alloc((Tmax, N, 2, env.F), np.float64)
-for T in (1, 2, 4, 8, 16):
-    steps = 64
+Ts = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8, 16]
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+with_obs = not (len(sys.argv) > 4 and sys.argv[4] == "noobs")
+Tmax = max(Ts)
+d_traj = env.alloc((Tmax, N, 2, env.F), np.float64) if with_obs else None
+for T in Ts:
     env.rollout(T, 1, 0, d_traj); env.sync()
     ms = C.c_float()
     L.cz_timer_start(h)
