@@ -170,7 +170,7 @@ def leg_closed_loop(env, d_obs, d_rew, d_term, d_trunc):
                                        "HIP events around graph replays of the closed loop; step + policy kernel + both boundaries")}
 
 
-def leg_cooking_policy(device_id):
+def cooking_policy_workload(device_id, K=512):
     """The one-step kernel under a policy that cooks: the reference's heuristic agent's action sequences (golden fixtures
     cfg2_coop_2agents, episodes that end with a delivered dish), every env on one of those worlds at its own phase of the
     episode; when an episode ends the env resets onto a world of the same pool and follows that world's sequence."""
@@ -200,7 +200,6 @@ def leg_cooking_policy(device_id):
         recs[e, soa.W_STATUS] = 0
     env.set_state(recs)
     # the action ring: follow each env through its episodes (termination -> one auto-reset pass -> next world from phase 0)
-    K = 512
     ring = np.zeros((K, N, A), dtype=np.int32)
     pool_word = int(recs[0, soa.W_POOL])
     for e in range(N):
@@ -213,6 +212,14 @@ def leg_cooking_policy(device_id):
                 k += 1                                                   # the auto-reset pass (its action is ignored)
                 ep_no += 1
                 j, s = int(L.cz_next_layout(env.env_id_base + e, ep_no, pool_word, P)), 0
+    return env, ring, P, T
+
+
+def leg_cooking_policy(device_id):
+    from cooking_zoo_amd import _native
+    K = 512
+    env, ring, P, T = cooking_policy_workload(device_id, K)
+    L, h, N, A = _native.lib(), env._h, env.num_envs, env.num_agents
     d_ring = env.alloc((K, N, A), np.int32)
     d_ring.from_host(ring)
     d_obs, d_rew = env.alloc((N, A, env.F), np.float64), env.alloc((N, A), np.float64)

@@ -948,6 +948,71 @@ struct Ops {
     // The same evaluation for WIDE recipe tables (graphs of up to 16 nodes): the node words come from the table in memory
     // (row: n, then per node  the device node word without its child field, the 16-bit child mask), the result has 16
     // bits.  A cold path by construction: batches whose book fits the compact tables never come here.
+    // The same for ALL compact recipe graphs of the env in one pass, cell-parallel (instances with up to 4 cells per lane; the
+    // 32x32 instance keeps recipe_marks above, whose scratch is 16x smaller).  A node asks two things of a cell: "is there an
+    // object of my class in an accepted state here / is this cell of my static class", and "are all my children satisfied
+    // HERE" (recipe.py:103: a child's matches count only where the parent's candidate is).  So:
+    //   1. every object ORs its kind bit (4 * class + state, the index `touch` uses) into an LDS word of its cell (one
+    //      ds_or_b64 for the whole wave, however many objects there are), and every cell lane reads its word back: K;
+    //   2. S (a bit per node, per cell lane): S_j = u_j(cell) && (S & children_j) == children_j, nodes from last to first
+    //      (children follow their parents in node_list); node j is marked iff S_j holds on some cell.
+    // No per-match loops, one LDS round trip for all recipes; `which` = bit r: evaluate recipe r (rows 9r.. of rowv); returns
+    // the marks bytes of those recipes (bits 8r + j), 0 for the others.
+    static __device__ __forceinline__ uint32_t recipe_marks_cells(const E &e, const Ctx &cx, uint32_t rowv, uint32_t which, int R,
+                                                                  uint64_t *__restrict__ tbl) {
+        static_assert(CPL <= 4, "scratch: 64 * CPL words");
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) tbl[cx.lane + 64 * q] = 0ull;
+#pragma unroll
+        for (int k = 0; k < OPL; ++k) {
+            const uint32_t w = e.d0[k];
+            const uint32_t kind = ((w >> 14) & 0x3Cu) | ((w >> 25) & 3u);
+            const uint32_t cell = __umul24((w >> 8) & 0xFFu, (uint32_t)cx.W) + (w & 0xFFu);
+            // (only the lanes of live objects take part: an atomic of all 64 lanes on one word would be serialised)
+            if (w & D_ALIVE) __hip_atomic_fetch_or(tbl + cell, 1ull << kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        // One wave owns this LDS region and the DS operations of a wave execute in order, so no hardware barrier is needed -
+        // but the compiler must not forward the zeroes above to the loads below on the path of a lane that skipped the atomic
+        // (what other lanes wrote in between is invisible to its per-thread view of memory).
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t Klo[CPL], Khi[CPL], S[CPL];
+        uint64_t valid[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const uint64_t K = tbl[cx.lane + 64 * q];
+            Klo[q] = (uint32_t)K; Khi[q] = (uint32_t)(K >> 32); S[q] = 0u;
+            valid[q] = ballot((cx.lane + 64 * q) < cx.C);
+        }
+        uint32_t marks = 0;
+#pragma nounroll
+        for (int r = 0; r < R; ++r) {
+            if (!((which >> r) & 1u)) continue;
+            const int n = (int)(rdl(rowv, 9 * r) & 0xFFu);
+            // Branch-free node body (a node whose children are not all marked has them nowhere, so it fails by itself), two nodes
+            // per trip so that the second one's compares overlap the first one's scalar work.
+#pragma unroll 2
+            for (int j = n - 1; j >= 0; --j) {
+                const uint32_t w = rdl(rowv, 9 * r + 1 + j);
+                const uint32_t need = (w & 0xFFu) << (8 * r), bit = 1u << (8 * r + j);
+                const bool is_static = (w & 0x200u) != 0u, is_dynamic = (w & 0x2000u) != 0u;
+                const uint32_t cls = (w >> 10) & 7u;
+                const uint64_t acc = is_dynamic ? (uint64_t)((w >> 24) & 0xFu) << ((w >> 14) & 0x3Cu) : 0ull;
+                const uint32_t acc_lo = (uint32_t)acc, acc_hi = (uint32_t)(acc >> 32);
+                uint64_t anywhere = 0ull;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    const uint64_t m_static = ballot((e.cell[q] & CELL_TYPE) == cls) & valid[q];
+                    const uint64_t m_dynamic = ballot(((Klo[q] & acc_lo) | (Khi[q] & acc_hi)) != 0u);
+                    const uint64_t ok = (is_static ? m_static : m_dynamic) & ballot((S[q] & need) == need);
+                    S[q] |= lanes(ok) ? bit : 0u;
+                    anywhere |= ok;
+                }
+                marks |= anywhere ? bit : 0u;
+            }
+        }
+        return marks;
+    }
     static __device__ __forceinline__ uint32_t recipe_marks_wide(const E &e, const Ctx &cx, const uint32_t *__restrict__ row,
                                                               uint64_t *__restrict__ locs) {
         const int n = (int)(rfl(row[0]) & 0xFFu);

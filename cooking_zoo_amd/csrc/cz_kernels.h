@@ -6,7 +6,8 @@ namespace cz {
 
 // Diagnostic build only (make prof -> libcookingzoo_hip_prof.so, -DCZ_PROFILE): s_memrealtime stamps (100 MHz, one clock for
 // the whole device, so that first start / last end of a launch can be read across XCDs) at phase boundaries,
-// written to a buffer of their own (Params::stamps); the shipped library contains none of this.
+// written to a buffer of their own (Params::stamps, 16 slots per env: 0..7 the phases, 8..10 inside the reward phase); the
+// shipped library contains none of this.
 #ifdef CZ_PROFILE
 #define CZ_STAMP(i)                                                                                    \
     do {                                                                                               \
@@ -14,7 +15,7 @@ namespace cz {
         __builtin_amdgcn_sched_barrier(0);                                                             \
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                 \
         __builtin_amdgcn_sched_barrier(0);                                                             \
-        if (lane == 0 && P.stamps) P.stamps[(size_t)env * 8 + (i)] = _t;                               \
+        if (lane == 0 && P.stamps) P.stamps[(size_t)env * 16 + (i)] = _t;                               \
     } while (0)
 #elif defined(CZ_ABLATE)
 // instruction-count ablation build (make ablate): CZ_STOP=i truncates the step after phase i; no stamps, no asm
@@ -62,7 +63,9 @@ struct Lds {
     int32_t sub[MAX_AGENTS][16];         // per observer: what to subtract (x8) for each axis code (first: two of its rows are read
                                          // with one ds_read2_b32, whose offsets reach 1 KB)
     uint16_t img[Img<CPL>::HALFWORDS];   // objects 6 hw each | cells 4 hw each | agents 8 hw each | the "absent" halfword
-    uint64_t locs[WIDE_NODES * CPL];     // recipe evaluation scratch: matched-location bit sets per node (CPL words each)
+    // recipe evaluation scratch: a kind-set word per cell (recipe_marks_cells; instances with up to 4 cells per lane) or
+    // matched-location bit sets per node, CPL words each (recipe_marks of the 32x32 instance, recipe_marks_wide)
+    uint64_t locs[(CPL <= 4 ? 64 : WIDE_NODES) * CPL];
 };
 
 // Memory access helpers: a wave-uniform base pointer plus a 32-bit unsigned per-lane byte offset, which the backend
@@ -210,8 +213,12 @@ __device__ __forceinline__ void all_marks(const Params &P, Env<OPL, CPL, NA> &e,
             if (r < 2) lo |= m << (16 * r); else hi |= m << (16 * (r - 2));
         }
     } else {
+        if constexpr (CPL <= 4) {
+            lo = Ops<OPL, CPL, NA, 3>::recipe_marks_cells(e, cx, rowv, 0xFu, P.R, s.locs);
+        } else {
 #pragma nounroll
-        for (int r = 0; r < P.R; ++r) lo |= Ops<OPL, CPL, NA, 3>::recipe_marks(e, cx, rowv, 9 * r, s.locs) << (8 * r);
+            for (int r = 0; r < P.R; ++r) lo |= Ops<OPL, CPL, NA, 3>::recipe_marks(e, cx, rowv, 9 * r, s.locs) << (8 * r);
+        }
     }
     e.marks = lo; e.marks_hi = hi;
 }
@@ -483,15 +490,33 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
             const uint64_t relmask = ballot((nw & 0x2000u) != 0u && seen != 0u) & NODE_LANES;
             const uint64_t sensmask = ballot(kids != 0u && (mb & kids) == kids) & NODE_LANES;
             after = 0;
+            CZ_STAMP(8);
+            uint32_t which = 0u;                                    // the recipes to re-evaluate
+    #pragma nounroll
+            for (int r = 0; r < P.R; ++r) {
+                const bool visible = ((relmask >> (9 * r + 1)) & 0xFFull) != 0ull;
+                const bool sensitive = dt.statechg != 0u || ((sensmask >> (9 * r + 1)) & 0xFFull) != 0ull;
+                which |= (visible && sensitive ? 1u : 0u) << r;
+            }
+            uint32_t fresh = 0u;
+            if constexpr (CPL <= 4) {
+                if (which) {
+                    CZ_SETPRIO(3);
+                    fresh = O::recipe_marks_cells(e, cx, rowv, which, P.R, lds.locs);
+                }
+            }
+            CZ_STAMP(9);
     #pragma nounroll
             for (int r = 0; r < P.R; ++r) {
                 const uint32_t mb_r = (before >> (8 * r)) & 0xFF;
-                const bool visible = ((relmask >> (9 * r + 1)) & 0xFFull) != 0ull;
-                const bool sensitive = dt.statechg != 0u || ((sensmask >> (9 * r + 1)) & 0xFFull) != 0ull;
                 uint32_t ma = mb_r;
-                if (visible && sensitive) {
-                    CZ_SETPRIO(3);
-                    ma = O::recipe_marks(e, cx, rowv, 9 * r, lds.locs);
+                if ((which >> r) & 1u) {
+                    if constexpr (CPL <= 4) {
+                        ma = (fresh >> (8 * r)) & 0xFFu;
+                    } else {
+                        CZ_SETPRIO(3);
+                        ma = O::recipe_marks(e, cx, rowv, 9 * r, lds.locs);
+                    }
                 }
                 after |= ma << (8 * r);
                 if (ma != mb_r) {
@@ -509,6 +534,7 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
                     if (cx.lane == r && r < NA) o.myrew = x;                   // recipe r is agent r's (cooking_env.py:255-261)
                 }
             }
+            CZ_STAMP(10);
         }
         e.marks = after;
         o.header |= after != before;

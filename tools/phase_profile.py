@@ -18,7 +18,7 @@ env = CookingVecEnv(N, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "C
                     num_layouts=256, auto_reset=True)
 env.reset(return_obs=False)
 L, h = _native.lib(), env._h
-stamps = env.alloc((N, 8), np.uint64)
+stamps = env.alloc((N, 16), np.uint64)
 L.cz_debug_set_stamps(h, stamps.ptr)
 rng = np.random.default_rng(0)
 d_act = env.alloc((N, 2), np.int32)
@@ -39,7 +39,7 @@ for it in range(60):
     L.cz_timer_stop(h, C.byref(ms))
     if it >= 10:
         evt_us.append(ms.value * 1e3)
-    s = stamps.to_host().astype(np.int64)
+    s = stamps.to_host().astype(np.int64)[:, :8]
     if it >= 10:
         acc.append(np.diff(s, axis=1))
         spread.append(s[:, 0].max() - s[:, 0].min())
