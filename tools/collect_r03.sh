@@ -17,11 +17,13 @@ python3 tools/size_sweep.py 1 > $O/size_sweep.txt 2>&1
 python3 tools/size_sweep.py 0 32768 65536 131072 >> $O/size_sweep.txt 2>&1
 python3 tools/fuse_sweep.py 131072 > $O/fuse_sweep.txt 2>&1
 python3 tools/fuse_sweep.py 65536 >> $O/fuse_sweep.txt 2>&1
-for wt in 0 1; do echo "CZ_WT=$wt"; CZ_WT=$wt timeout 300 python3 tools/bench_configs.py cfg2_16k cfg4_shard cfg2_64k 2>/dev/null; done > $O/wt_ab.txt
+for wt in 0 1 2; do echo "CZ_WT=$wt"; CZ_WT=$wt timeout 400 python3 tools/bench_configs.py cfg2_16k cfg4_shard cfg3 cfg5 2>/dev/null | cut -c1-420; done > $O/wt_ab.txt
+(echo "== plain stores"; CZ_WT=0 python3 tools/fuse_sweep.py 4096 4,8,16,32,64,128 1024; echo "== streaming stores"; CZ_WT=2 python3 tools/fuse_sweep.py 4096 4,8,16,32,64,128 1024; echo "== no observation"; python3 tools/fuse_sweep.py 4096 8,32,128 1024 noobs) > $O/fuse_sweep_4096.txt 2>&1
 # 4. instruction counts per action stream, launch time per action stream, phase stamps
 bash tools/interact_probe.sh > $O/interact_probe.txt 2>&1
 python3 tools/mode_timing.py > $O/mode_timing.txt 2>&1
 for m in stay random; do python3 tools/phase_profile.py 4096 $m; done > $O/phase_profile.txt 2>&1
+python3 tools/cook_profile.py 200 > $O/cook_profile.txt 2>&1
 python3 tools/rot_probe.py > $O/rot_probe.txt 2>&1
 # 5. the bench lines: default, the driver's K = 20, boundary-ordered
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
