@@ -948,70 +948,101 @@ struct Ops {
     // The same evaluation for WIDE recipe tables (graphs of up to 16 nodes): the node words come from the table in memory
     // (row: n, then per node  the device node word without its child field, the 16-bit child mask), the result has 16
     // bits.  A cold path by construction: batches whose book fits the compact tables never come here.
-    // The same for ALL compact recipe graphs of the env in one pass, cell-parallel (instances with up to 4 cells per lane; the
-    // 32x32 instance keeps recipe_marks above, whose scratch is 16x smaller).  A node asks two things of a cell: "is there an
-    // object of my class in an accepted state here / is this cell of my static class", and "are all my children satisfied
-    // HERE" (recipe.py:103: a child's matches count only where the parent's candidate is).  So:
-    //   1. every object ORs its kind bit (4 * class + state, the index `touch` uses) into an LDS word of its cell (one
-    //      ds_or_b64 for the whole wave, however many objects there are), and every cell lane reads its word back: K;
-    //   2. S (a bit per node, per cell lane): S_j = u_j(cell) && (S & children_j) == children_j, nodes from last to first
-    //      (children follow their parents in node_list); node j is marked iff S_j holds on some cell.
-    // No per-match loops, one LDS round trip for all recipes; `which` = bit r: evaluate recipe r (rows 9r.. of rowv); returns
-    // the marks bytes of those recipes (bits 8r + j), 0 for the others.
+    // The same for ALL compact recipe graphs of the env in one pass (instances with up to 4 cells per lane; the 32x32 instance
+    // keeps recipe_marks above, whose scratch is 16x smaller).  A node asks two things of a cell: "is there an object of my
+    // class in an accepted state here / is this cell of my static class", and "are all my children satisfied HERE"
+    // (recipe.py:103: a child's matches count only where the parent's candidate is); node j is marked iff both hold on some
+    // cell.  `which` = bit r: evaluate recipe r (rows 9r.. of rowv); returns the marks bytes of those recipes (bits 8r + j), 0
+    // for the others.
+    // bitwise OR over the wave (DPP row shifts and row broadcasts; the result is wave-uniform)
+    static __device__ __forceinline__ uint32_t wave_or(uint32_t x) {
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);      // row_shr:1
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);      // row_shr:2
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);      // row_shr:4
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);      // row_shr:8: lane 15 of a row = the row
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xF, 0xF, true);      // row_bcast:15
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xF, 0xF, true);      // row_bcast:31
+        return rdl(x, 63);
+    }
+    // Node-parallel where the nodes are (their lanes), object-parallel where the objects are, cell-parallel for the rest:
+    //   B. every node lane (lane 9r + 1 + j of rowv) ORs its bit 8r + j into NK[kind] for each kind its class / accept mask
+    //      takes (dynamic class) or into NS[cell type] (static class);
+    //   C. every live object reads NK[its kind] - the nodes that accept it - and ORs that into U[its cell];
+    //   D. every cell lane reads U[cell] | NS[its type]: the nodes whose class condition holds on this cell;
+    //   E. S (a bit per node, per cell lane): S_j = U_j && (S & children_j) == children_j, nodes from last to first;
+    //   F. marks = OR of S over the cells.
+    // Four LDS round trips of one or two instructions each, no per-match and no per-object loops; the only serial part is E,
+    // five vector and four scalar instructions per node.
     static __device__ __forceinline__ uint32_t recipe_marks_cells(const E &e, const Ctx &cx, uint32_t rowv, uint32_t which, int R,
-                                                                  uint64_t *__restrict__ tbl) {
-        static_assert(CPL <= 4, "scratch: 64 * CPL words");
+                                                                  uint64_t *__restrict__ tbl64) {
+        static_assert(CPL <= 4, "scratch: 64 * CPL + 8 words of 64 bits");
+        uint32_t *const U = reinterpret_cast<uint32_t *>(tbl64);       // [64 * CPL] node bits per cell
+        uint32_t *const NK = U + 64 * CPL;                              // [64] node bits per object kind (4 * class + state)
+        uint32_t *const NS = NK + 64;                                   // [8] node bits per static cell type
+        // (the lane number through an opaque move: what is computed from it below - node lane or not, which recipe, which node -
+        // would otherwise be hoisted to the top of the kernel and live in scalar register pairs through every step)
+        uint32_t lane = (uint32_t)cx.lane;
+        asm volatile("" : "+v"(lane));
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) tbl[cx.lane + 64 * q] = 0ull;
+        for (int q = 0; q < CPL; ++q) U[lane + 64 * q] = 0u;
+        NK[lane] = 0u;
+        if (lane < 8u) NS[lane] = 0u;
+        // (B and C without branches: a lane with nothing to add ORs 0 into a word of its own, so that idle lanes neither switch
+        // exec nor pile up on one address, where an LDS atomic would take them one after the other)
+        {   // B
+            const uint32_t r_of = (lane * 57u) >> 9, j_of = lane - 9u * r_of - 1u;          // lane / 9, lane % 9 - 1
+            const bool mine = r_of < (uint32_t)R && j_of < (uint32_t)MAX_NODES && ((which >> r_of) & 1u) != 0u;
+            const uint32_t w = mine ? rowv : 0u;                                            // (rows are zero-padded behind their nodes)
+            const uint32_t nb = 1u << ((8u * r_of + j_of) & 31u);
+            // (selects by arithmetic on 0 / ~0 words: lane masks would occupy a pair of scalar registers each)
+            const uint32_t base = (w >> 14) & 0x3Cu, acc = ((w >> 24) & 0xFu) & (0u - ((w >> 13) & 1u));
 #pragma unroll
-        for (int k = 0; k < OPL; ++k) {
-            const uint32_t w = e.d0[k];
-            const uint32_t kind = ((w >> 14) & 0x3Cu) | ((w >> 25) & 3u);
-            const uint32_t cell = __umul24((w >> 8) & 0xFFu, (uint32_t)cx.W) + (w & 0xFFu);
-            // (only the lanes of live objects take part: an atomic of all 64 lanes on one word would be serialised)
-            if (w & D_ALIVE) __hip_atomic_fetch_or(tbl + cell, 1ull << kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            for (uint32_t st = 0; st < 4u; ++st) {
+                const uint32_t on = 0u - ((acc >> st) & 1u);
+                __hip_atomic_fetch_or(NK + lane + ((base + st - lane) & on), nb & on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            const uint32_t stat = 0u - ((w >> 9) & 1u);                                     // NS follows NK: word 64 + type
+            __hip_atomic_fetch_or(NK + lane + ((64u + ((w >> 10) & 7u) - lane) & stat), nb & stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
         // One wave owns this LDS region and the DS operations of a wave execute in order, so no hardware barrier is needed -
-        // but the compiler must not forward the zeroes above to the loads below on the path of a lane that skipped the atomic
-        // (what other lanes wrote in between is invisible to its per-thread view of memory).
+        // but the compiler must not forward a lane's own earlier stores to its loads below (what other lanes wrote in between
+        // is invisible to its per-thread view of memory).
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        uint32_t Klo[CPL], Khi[CPL], S[CPL];
-        uint64_t valid[CPL];
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-            const uint64_t K = tbl[cx.lane + 64 * q];
-            Klo[q] = (uint32_t)K; Khi[q] = (uint32_t)(K >> 32); S[q] = 0u;
-            valid[q] = ballot((cx.lane + 64 * q) < cx.C);
+        for (int k = 0; k < OPL; ++k) {   // C
+            const uint32_t w = e.d0[k];
+            const uint32_t alive = 0u - ((w >> 24) & 1u);
+            static_assert(D_ALIVE == 1u << 24, "bit 24");
+            const uint32_t kind = ((w >> 14) & 0x3Cu) | ((w >> 25) & 3u);
+            const uint32_t cell = __umul24((w >> 8) & 0xFFu, (uint32_t)cx.W) + (w & 0xFFu);
+            const uint32_t nodes = NK[kind];
+            __hip_atomic_fetch_or(U + lane + ((cell - lane) & alive), nodes & alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
-        uint32_t marks = 0;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t Uq[CPL], S[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {   // D
+            const uint32_t st = NS[e.cell[q] & CELL_TYPE];
+            Uq[q] = U[lane + 64 * q] | ((lane + 64u * q) < (uint32_t)cx.C ? st : 0u);
+            S[q] = 0u;
+        }
 #pragma nounroll
-        for (int r = 0; r < R; ++r) {
+        for (int r = 0; r < R; ++r) {     // E
             if (!((which >> r) & 1u)) continue;
             const int n = (int)(rdl(rowv, 9 * r) & 0xFFu);
-            // Branch-free node body (a node whose children are not all marked has them nowhere, so it fails by itself), two nodes
-            // per trip so that the second one's compares overlap the first one's scalar work.
-#pragma unroll 2
+#pragma nounroll
             for (int j = n - 1; j >= 0; --j) {
-                const uint32_t w = rdl(rowv, 9 * r + 1 + j);
-                const uint32_t need = (w & 0xFFu) << (8 * r), bit = 1u << (8 * r + j);
-                const bool is_static = (w & 0x200u) != 0u, is_dynamic = (w & 0x2000u) != 0u;
-                const uint32_t cls = (w >> 10) & 7u;
-                const uint64_t acc = is_dynamic ? (uint64_t)((w >> 24) & 0xFu) << ((w >> 14) & 0x3Cu) : 0ull;
-                const uint32_t acc_lo = (uint32_t)acc, acc_hi = (uint32_t)(acc >> 32);
-                uint64_t anywhere = 0ull;
+                const uint32_t need = (rdl(rowv, 9 * r + 1 + j) & 0xFFu) << (8 * r), bit = 1u << (8 * r + j);
 #pragma unroll
-                for (int q = 0; q < CPL; ++q) {
-                    const uint64_t m_static = ballot((e.cell[q] & CELL_TYPE) == cls) & valid[q];
-                    const uint64_t m_dynamic = ballot(((Klo[q] & acc_lo) | (Khi[q] & acc_hi)) != 0u);
-                    const uint64_t ok = (is_static ? m_static : m_dynamic) & ballot((S[q] & need) == need);
-                    S[q] |= lanes(ok) ? bit : 0u;
-                    anywhere |= ok;
-                }
-                marks |= anywhere ? bit : 0u;
+                for (int q = 0; q < CPL; ++q) S[q] |= ((S[q] & need) == need) ? (Uq[q] & bit) : 0u;
             }
         }
-        return marks;
+        uint32_t all = S[0];
+#pragma unroll
+        for (int q = 1; q < CPL; ++q) all |= S[q];
+        return wave_or(all);              // F
     }
     static __device__ __forceinline__ uint32_t recipe_marks_wide(const E &e, const Ctx &cx, const uint32_t *__restrict__ row,
                                                               uint64_t *__restrict__ locs) {

@@ -63,9 +63,10 @@ struct Lds {
     int32_t sub[MAX_AGENTS][16];         // per observer: what to subtract (x8) for each axis code (first: two of its rows are read
                                          // with one ds_read2_b32, whose offsets reach 1 KB)
     uint16_t img[Img<CPL>::HALFWORDS];   // objects 6 hw each | cells 4 hw each | agents 8 hw each | the "absent" halfword
-    // recipe evaluation scratch: a kind-set word per cell (recipe_marks_cells; instances with up to 4 cells per lane) or
-    // matched-location bit sets per node, CPL words each (recipe_marks of the 32x32 instance, recipe_marks_wide)
-    uint64_t locs[(CPL <= 4 ? 64 : WIDE_NODES) * CPL];
+    // recipe evaluation scratch: node bits per cell, per object kind and per cell type (recipe_marks_cells; instances with up
+    // to 4 cells per lane) or matched-location bit sets per node, CPL words each (recipe_marks of the 32x32 instance,
+    // recipe_marks_wide)
+    uint64_t locs[CPL <= 4 ? 64 * CPL + 8 : WIDE_NODES * CPL];
 };
 
 // Memory access helpers: a wave-uniform base pointer plus a 32-bit unsigned per-lane byte offset, which the backend
