@@ -488,51 +488,57 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
             const uint32_t seen = (uint32_t)(dt.kinds >> ((nw >> 14) & 0x3Cu)) & ((nw >> 24) & 0xFu);
             const uint32_t kids = nw & 0xFFu, mb = (before >> (8u * (r_of & 3u))) & 0xFFu;
             constexpr uint64_t NODE_LANES = 0x1FEull | (0x1FEull << 9) | (0x1FEull << 18) | (0x1FEull << 27);
-            const uint64_t relmask = ballot((nw & 0x2000u) != 0u && seen != 0u) & NODE_LANES;
-            const uint64_t sensmask = ballot(kids != 0u && (mb & kids) == kids) & NODE_LANES;
-            after = 0;
+            const bool rel = (nw & 0x2000u) != 0u && seen != 0u, sens = kids != 0u && (mb & kids) == kids;
+            // the rewards of recipe r whose marks went from mb_r to ma (cooking_env.py:255-261, recipe.py:36-40)
+            const auto reward_of = [&](int r, uint32_t mb_r, uint32_t ma) {
+                // goals_completed sums (recipe.py:36-40): open goal slots before / after
+                const uint32_t countmask = (uint32_t)((ballot((nw & 0x100u) != 0u) >> (9 * r + 1)) & 0xFFull);
+                const int goals_before = __popc(~mb_r & countmask), goals_after = __popc(~ma & countmask);
+                const bool completed = ma & 1, completion_before = mb_r & 1;
+                const bool malus = !completed && completion_before, bonus = completed && !completion_before;
+                const KParams kp = late_params(kp_off);
+                double x = 0.0;
+                x += (double)(goals_before - goals_after) * kp->node_reward;
+                x += (bonus ? 1.0 : 0.0) * kp->recipe_reward;
+                x += (malus ? 1.0 : 0.0) * kp->recipe_penalty;
+                x += kp->time_penalty_step;
+                if (cx.lane == r && r < NA) o.myrew = x;                       // recipe r is agent r's (cooking_env.py:255-261)
+            };
             CZ_STAMP(8);
-            uint32_t which = 0u;                                    // the recipes to re-evaluate
-    #pragma nounroll
-            for (int r = 0; r < P.R; ++r) {
-                const bool visible = ((relmask >> (9 * r + 1)) & 0xFFull) != 0ull;
-                const bool sensitive = dt.statechg != 0u || ((sensmask >> (9 * r + 1)) & 0xFFull) != 0ull;
-                which |= (visible && sensitive ? 1u : 0u) << r;
-            }
-            uint32_t fresh = 0u;
             if constexpr (CPL <= 4) {
+                // "some node of recipe r" for both tests in one OR over the wave: bit r = visible, bit 4 + r = sensitive
+                const uint32_t flags = (rel ? 1u : 0u) | (sens ? 16u : 0u);
+                const uint32_t any = O::wave_or(lanes(NODE_LANES) ? (flags << (r_of & 3u)) : 0u);
+                const uint32_t which = any & (dt.statechg != 0u ? 0xFu : (any >> 4)) & ((1u << P.R) - 1u);   // the recipes to re-evaluate
                 if (which) {
                     CZ_SETPRIO(3);
-                    fresh = O::recipe_marks_cells(e, cx, rowv, which, P.R, lds.locs);
+                    const uint32_t fresh = O::recipe_marks_cells(e, cx, rowv, which, P.R, lds.locs);
+                    CZ_STAMP(9);
+                    const uint32_t bytes = ((which * 0x204081u) & 0x01010101u) * 0xFFu;    // bit r -> byte r
+                    after = (before & ~bytes) | (fresh & bytes);
+                    if (after != before) {
+#pragma nounroll
+                        for (int r = 0; r < P.R; ++r) {
+                            const uint32_t mb_r = (before >> (8 * r)) & 0xFFu, ma = (after >> (8 * r)) & 0xFFu;
+                            if (ma != mb_r) reward_of(r, mb_r, ma);
+                        }
+                    }
                 }
-            }
-            CZ_STAMP(9);
-    #pragma nounroll
-            for (int r = 0; r < P.R; ++r) {
-                const uint32_t mb_r = (before >> (8 * r)) & 0xFF;
-                uint32_t ma = mb_r;
-                if ((which >> r) & 1u) {
-                    if constexpr (CPL <= 4) {
-                        ma = (fresh >> (8 * r)) & 0xFFu;
-                    } else {
+            } else {
+                const uint64_t relmask = ballot(rel) & NODE_LANES, sensmask = ballot(sens) & NODE_LANES;
+                after = 0;
+#pragma nounroll
+                for (int r = 0; r < P.R; ++r) {
+                    const uint32_t mb_r = (before >> (8 * r)) & 0xFF;
+                    const bool visible = ((relmask >> (9 * r + 1)) & 0xFFull) != 0ull;
+                    const bool sensitive = dt.statechg != 0u || ((sensmask >> (9 * r + 1)) & 0xFFull) != 0ull;
+                    uint32_t ma = mb_r;
+                    if (visible && sensitive) {
                         CZ_SETPRIO(3);
                         ma = O::recipe_marks(e, cx, rowv, 9 * r, lds.locs);
                     }
-                }
-                after |= ma << (8 * r);
-                if (ma != mb_r) {
-                    // goals_completed sums (recipe.py:36-40): open goal slots before / after
-                    const uint32_t countmask = (uint32_t)((ballot((nw & 0x100u) != 0u) >> (9 * r + 1)) & 0xFFull);
-                    const int goals_before = __popc(~mb_r & countmask), goals_after = __popc(~ma & countmask);
-                    const bool completed = ma & 1, completion_before = mb_r & 1;
-                    const bool malus = !completed && completion_before, bonus = completed && !completion_before;
-                    const KParams kp = late_params(kp_off);
-                    double x = 0.0;
-                    x += (double)(goals_before - goals_after) * kp->node_reward;
-                    x += (bonus ? 1.0 : 0.0) * kp->recipe_reward;
-                    x += (malus ? 1.0 : 0.0) * kp->recipe_penalty;
-                    x += kp->time_penalty_step;
-                    if (cx.lane == r && r < NA) o.myrew = x;                   // recipe r is agent r's (cooking_env.py:255-261)
+                    after |= ma << (8 * r);
+                    if (ma != mb_r) reward_of(r, mb_r, ma);
                 }
             }
             CZ_STAMP(10);

@@ -43,7 +43,8 @@ for k in range(K):
     # inside the reward phase (only waves in which an object moved or changed write these): 3 -> 8 filter, 8 -> 9 evaluation
     # of the recipe graphs (0 when the filter says no), 9 -> 10 rewards, 10 -> 4 flags
     tw = (s16[:, 8] > 0) & ~was_done
-    sub.append(np.stack([s16[tw, 8] - s16[tw, 3], s16[tw, 9] - s16[tw, 8], s16[tw, 10] - s16[tw, 9], s16[tw, 4] - s16[tw, 10], s16[tw, 4] - s16[tw, 3]], axis=1))
+    s9 = np.where(s16[:, 9] > 0, s16[:, 9], s16[:, 8])             # (no evaluation: stamp 9 is not written)
+    sub.append(np.stack([s16[tw, 8] - s16[tw, 3], s9[tw] - s16[tw, 8], s16[tw, 10] - s9[tw], s16[tw, 4] - s16[tw, 10], s16[tw, 4] - s16[tw, 3]], axis=1))
     evt.append(ms.value * 1e3)
     life = s[:, 7] - s[:, 0]
     d = np.diff(s, axis=1)
