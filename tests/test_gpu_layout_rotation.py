@@ -67,6 +67,34 @@ def test_rotating_pool_is_bit_exact_and_uses_new_layouts():
     env.close()
 
 
+def test_non_blocking_rotation_replays_from_its_events():
+    """rotate_layouts(blocking=False): a refill whose layouts the background process has not finished yet is retried at the next
+    call instead of waited for, so the schedule depends on timing - but `rotation_events` still says what was switched /
+    replaced before which step, and the oracle fed with them stays bit-exact."""
+    from oracle_binding import VecOracle
+    n, T = 256, 700
+    env = make(n, 20, 32)
+    orc = VecOracle.from_vec_env(env)
+    assert np.array_equal(bits(env.reset()), bits(orc.reset()))
+    env.rotate_layouts(23, groups=2, seed=9, prefetch=1, blocking=False)
+    seen = 0
+    rng = np.random.default_rng(6)
+    for t in range(T):
+        for ev in env.rotation_events[seen:]:
+            orc.apply_rotation_event(ev)
+        seen = len(env.rotation_events)
+        acts = rng.integers(0, env.n_actions, size=(n, 2), dtype=np.int32)
+        og, rg, tg, ug = env.step(acts)
+        oo, ro, to, uo = orc.step(acts)
+        assert np.array_equal(bits(og), bits(oo)), f"observation at step {t}"
+        assert np.array_equal(bits(rg), bits(ro)) and np.array_equal(tg, to) and np.array_equal(ug, uo), f"rewards / flags at step {t}"
+    assert np.array_equal(strip(env.get_state()), orc.records)
+    refills = [ev for ev in env.rotation_events if ev[1] == "layouts"]
+    switches = [ev for ev in env.rotation_events if ev[1] == "group"]
+    assert len(switches) >= 2 and len(refills) >= 1, (len(switches), len(refills))
+    env.close()
+
+
 def test_rotation_keeps_the_step_rate():
     """Device-resident stepping (2000 steps as 40 ring calls of 50) with the pool rotating (switch every 500 steps, refills
     prepared ahead by the background thread) against the same run on a static pool: within 3 %."""
