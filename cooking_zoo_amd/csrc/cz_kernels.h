@@ -711,19 +711,17 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         const double myrew = o.myrew;
         if (o.stepped) ret += myrew;
         const KParams kp = CZ_LATE_STEP();
+        // The statistics are a read-modify-write of words in memory (across launches: device-scope loads, write-through stores,
+        // like the record).  A wave that ends an episode issues the loads here and adds / stores behind the encode: the round
+        // trip (~1 us after a launch boundary) used to make exactly these waves the last ones of a launch in which nobody acts.
+        uint32_t su_old = 0u;
+        double sf_old = 0.0, ret_done = 0.0;
         if (o.finished) {
-            uint32_t *su = kp->stat_u + (size_t)env * SU_WORDS;
-            double *sf = kp->stat_f + (size_t)env * SF_WORDS;
-            // (read-modify-write across launches: device-scope loads, write-through stores, like the record)
-            const auto bump = [&](int word, uint32_t by) { strec<uint32_t>(chained, su, (uint32_t)word * 4u, ldrec<uint32_t>(chained, su, (uint32_t)word * 4u) + by); };
-            if (lane == 0) {
-                bump(SU_EPISODES, 1u); bump(SU_LENSUM, e.t); bump(SU_TRUNC, (uint32_t)o.trunc); bump(SU_TERM, (uint32_t)o.term);
-            }
-            if (lane < NA) {
-                const uint32_t root = Pt.wide ? (((lane < 2 ? e.marks : e.marks_hi) >> (16 * (lane & 1))) & 1u) : ((e.marks >> (8 * lane)) & 1u);
-                bump(SU_COMPLETED0 + lane, root);
-                strec<double>(chained, sf, (uint32_t)(SF_SUM0 + lane) * 8u, ldrec<double>(chained, sf, (uint32_t)(SF_SUM0 + lane) * 8u) + ret);
-            }
+            const uint32_t *su = kp->stat_u + (size_t)env * SU_WORDS;
+            const double *sf = kp->stat_f + (size_t)env * SF_WORDS;
+            su_old = ldrec<uint32_t>(chained, su, ((uint32_t)lane & 15u) * 4u);
+            sf_old = ldrec<double>(chained, sf, (uint32_t)(SF_SUM0 + ((uint32_t)lane & 3u)) * 8u);
+            ret_done = ret;
             ret = 0.0;
         }
         // ---- outputs of this step.  One wave-uniform base pointer per array and a 32-bit per-lane offset (cz_rollout checks
@@ -757,6 +755,16 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
             // (env row x row length: a 32 x 32 -> 64-bit product, two scalar multiplies)
             observe(Pt, e, cx, lds, lut, dsc, submask, Pt.obs + (uint64_t)(uint32_t)row * (uint64_t)(uint32_t)(NA * Pt.F), img_objs, img_cells);
             img_objs = false; img_cells = false;
+        }
+        if (o.finished) {                      // (the state is still that of the finished episode: the reset is the next pass)
+            uint32_t *su = kp->stat_u + (size_t)env * SU_WORDS;
+            double *sf = kp->stat_f + (size_t)env * SF_WORDS;
+            const uint32_t a_of = (uint32_t)lane - SU_COMPLETED0;               // lane SU_COMPLETED0 + a: recipe a completed?
+            const uint32_t root = Pt.wide ? (((a_of < 2u ? e.marks : e.marks_hi) >> (16u * (a_of & 1u))) & 1u) : ((e.marks >> (8u * (a_of & 3u))) & 1u);
+            const uint32_t inc = lane == (int)SU_EPISODES ? 1u : lane == (int)SU_LENSUM ? e.t : lane == (int)SU_TRUNC ? (uint32_t)o.trunc
+                                 : lane == (int)SU_TERM ? (uint32_t)o.term : a_of < (uint32_t)NA ? root : 0u;
+            if (lane < (int)SU_COMPLETED0 + NA && lane != (int)SU_STEPS) strec<uint32_t>(chained, su, (uint32_t)lane * 4u, su_old + inc);
+            if (lane < NA) strec<double>(chained, sf, (uint32_t)(SF_SUM0 + lane) * 8u, sf_old + ret_done);
         }
         CZ_STAMP(6);
     }
