@@ -634,8 +634,8 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
             if ((++polls & 255u) == 0u) {                   // ~every 50 us: somebody else gave up, or two seconds have passed
                 const uint64_t now = wall_clock64();        // 100 MHz
                 if (t_begin == 0) t_begin = now;
-#ifdef CZ_PROFILE
-                uint32_t *const errw = nullptr;
+#ifdef CZ_PROFILE                // (the diagnostic build has no such word and never launches this kernel: cz_set_overlap refuses)
+                uint32_t *const errw = reinterpret_cast<uint32_t *>(CZ_LATE_STEP()->stamps);
 #else
                 uint32_t *const errw = CZ_LATE_STEP()->chain_err;
 #endif
