@@ -593,7 +593,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     constexpr int EPW = envs_per_wg<CPL>();
     __shared__ Lds<CPL> lds_all[EPW];
     __shared__ double lut[LUT_SIZE];
-    const int lane = (int)(threadIdx.x & 63u);
+    int lane = (int)(threadIdx.x & 63u);
     const int wave = (int)rfl(threadIdx.x >> 6);
     // (the last workgroup may be partial: its spare waves shadow the last env up to the barrier, then leave)
     const int env_raw = (int)blockIdx.x * EPW + wave;
@@ -680,9 +680,11 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
 #pragma nounroll
     for (int t = 0; t < T; ++t) {
         // The fused kernel re-reads its argument block every step (scalar loads that hit the constant cache): nothing of
-        // it then stays live across the loop's back edge, which is what used to spill ~90 SGPRs.
+        // it then stays live across the loop's back edge, which is what used to spill ~90 SGPRs.  The kernel of overlapped
+        // launches, held to 96 scalar registers, does the same behind its wait (59 -> 24 spilled SGPRs together with the fresh
+        // lane number below).
         Params Pt;
-        if (FUSED) {
+        if (FUSED || CHAIN) {
             static_assert(sizeof(Params) % 8 == 0, "copied as 64-bit words");
             typedef uint64_t __attribute__((may_alias)) word_t;
             const __attribute__((address_space(4))) word_t *src = (const __attribute__((address_space(4))) word_t *)CZ_LATE_STEP();
@@ -704,6 +706,9 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         if (Pt.stop == 2 || Pt.stop == 3) return;
 #endif
         CZ_STAMP(4);
+        // (overlapped launches: what the step's phases derived from the lane number - lane masks in scalar pairs - is not kept
+        // for the output phase but made again from an opaque copy: a compare costs less than a spill and a reload)
+        if (CHAIN) { asm volatile("" : "+v"(lane)); cx.lane = lane; }
         cells_dirty |= dt.cells != 0;
         objs_dirty |= (dt.touched | dt.interacted | dt.moved) != 0;
         header_dirty |= o.header;
