@@ -147,6 +147,30 @@ def timed_ring(env, K, ring, outs, reps=3):
     return best * 1e3 / K
 
 
+def leg_fused(env, K):
+    """the same work fused: T = 32 steps per launch with the on-device action stream and a [T][N][A][F] trajectory buffer"""
+    N, A, T = env.num_envs, env.num_agents, 32
+    d_traj = env.alloc((T, N, A, env.F), np.float64)
+    d_r = env.alloc((T, N, A), np.float64)
+    d_te = env.alloc((T, N, A), np.uint8)
+    d_tr = env.alloc((T, N, A), np.uint8)
+    try:
+        reps = max(2, min(K, 2000) // T)
+        env.rollout(T, 1, 0, d_traj, d_r, d_te, d_tr)
+        env.sync()
+        f0 = env.stats()["env_steps"]
+        t0 = time.perf_counter()
+        for r in range(reps):
+            env.rollout(T, 1, (r + 1) * T, d_traj, d_r, d_te, d_tr)
+        env.sync()
+        dtf = time.perf_counter() - t0
+        return {"env_steps_per_s_per_gpu": (env.stats()["env_steps"] - f0) / dtf, "steps_per_launch": T,
+                "ms_per_step": dtf * 1e3 / (reps * T), "api": "cz_rollout, obs trajectory [T][N][A][F] in HBM"}
+    finally:
+        for b in (d_traj, d_r, d_te, d_tr):
+            b.free()
+
+
 def leg_closed_loop(env, d_obs, d_rew, d_term, d_trunc):
     """What a reinforcement-learning loop gets: cz_step_device, then a kernel of the caller that turns the observation into the
     next actions, then the next step - every step waits for a policy that waits for the step before it.  (The policy here is
@@ -295,6 +319,33 @@ def leg_configs(device_id, which=("config3", "config5", "config4_shard")):
     return out
 
 
+def guarded(fn, *a, **kw):
+    """an extra leg of the line: its result, or {"error": ...} - never an exception that would lose the headline"""
+    try:
+        return fn(*a, **kw)
+    except BaseException as exc:                     # noqa: BLE001  (incl. MemoryError; KeyboardInterrupt is re-raised)
+        if isinstance(exc, KeyboardInterrupt):
+            raise
+        import traceback
+        return {"error": f"{type(exc).__name__}: {exc}", "where": traceback.format_exc(limit=3).strip().splitlines()[-3:]}
+
+
+CFG4_ENVS_PER_GPU, CFG4_K = 32768, 100        # BASELINE config 4: 262 144 envs over 8 GPUs; its timed regions are 100 steps long
+
+
+def config4_block(world, per_rank, b_alg4):
+    """the `config4` object of the line from every rank's region timings (per_rank[r]: elapsed_s, env_steps, env_id_base, envs)"""
+    a4 = aggregate(per_rank, CFG4_K)
+    total = sum(p["envs"] for p in per_rank)
+    out = {"workload": f"BASELINE config 4 shape: {CFG4_ENVS_PER_GPU} envs per GPU x {world} GPU(s) = {total} envs, coop_test, 2 agents, global env ids, "
+                       f"statistics all-gather over RCCL; one launch per step (graph replay), {CFG4_K}-step regions between all-rank barriers",
+           "envs": total, "shards": [[p["env_id_base"], p["envs"]] for p in per_rank],
+           "value": a4["value"], "unit": "env-steps/s", "ms_per_step": a4["ms_per_step"], "value_min": a4["value_min"], "value_max": a4["value_max"]}
+    if b_alg4 is not None:
+        out["roofline"] = roofline_block(b_alg4, CFG4_ENVS_PER_GPU, a4["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,false>", "wall clock of the slowest rank per region")
+    return out
+
+
 def with_deadline(fn, seconds):
     """fn() on a helper thread; -> (finished, result or exception)."""
     box = {}
@@ -416,8 +467,11 @@ def worker_body(args, rdzv, overlap, note):
     if args.dry_run:
         if overlap and sim and (sim == "1" or int(sim) == rank + 100):
             raise RuntimeError("simulated: an overlapped launch gave up waiting for its predecessor")
+        b4, n4 = czd.shard_range(CFG4_ENVS_PER_GPU * world, world, rank)
         mine = {"elapsed_s": [1e-3 * (rank + 1 + 0.01 * r) for r in range(R)], "env_steps": [K * count] * R,
-                "kernel_us": [1.0] * R, "stats": {"env_steps": K * count * R}}
+                "kernel_us": [1.0] * R, "stats": {"env_steps": K * count * R},
+                "device_id": local_rank, "rank": rank, "env_id_base": begin, "cfg4": {"env_id_base": b4, "envs": n4,
+                "elapsed_s": [1e-2 * (rank + 1)] * 2, "env_steps": [CFG4_K * n4] * 2, "kernel_us": [0.0] * 2}}
         every = [json.loads(b) for b in rdzv.all_gather(json.dumps(mine).encode())]
         if rank == 0:
             line = {"metric": "env-steps/sec at N parallel envs (1/2/4/8 GPU) + achieved HBM GB/s", "unit": "env-steps/s",
@@ -425,8 +479,11 @@ def worker_body(args, rdzv, overlap, note):
                     "dtype": "u8/u32 state, f64 obs+reward", "data": "DRY RUN: no GPU work, made-up timings (INVALID as a result)",
                     "config": {"workload": f"dry run, {N} envs per rank x {world} rank(s)"},
                     "shards": [czd.shard_range(N * world, world, r) for r in range(world)],
-                    "stats_total_env_steps": sum(e["stats"]["env_steps"] for e in every)}
+                    "stats_total_env_steps": sum(e["stats"]["env_steps"] for e in every),
+                    "device_ids": [e["device_id"] for e in every], "env_id_bases": [e["env_id_base"] for e in every]}
             line.update(aggregate(every, K))
+            if world > 1 and not args.no_extras:
+                line["config4"] = config4_block(world, [e["cfg4"] for e in every], None)
             if note:
                 line["overlap_fallback"] = note
             emit(line)
@@ -532,9 +589,10 @@ def worker_body(args, rdzv, overlap, note):
     # statistics exchange below is that config's only collective); every rank times the same K-step regions between barriers
     cfg4_every = None
     if world > 1 and not args.no_extras:
-        n4, K4, R4 = 32768, 100, 5
+        K4, R4 = CFG4_K, 5
+        base4, n4 = czd.shard_range(CFG4_ENVS_PER_GPU * world, world, rank)
         env4 = CookingVecEnv(n4, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3",
-                             num_layouts=256, layout_seed=0, auto_reset=True, device_id=local_rank, env_id_base=rank * n4)
+                             num_layouts=256, layout_seed=0, auto_reset=True, device_id=local_rank, env_id_base=base4)
         env4.reset(return_obs=False)
         d_ring4 = env4.alloc((16, n4, 2), np.int32)
         d_ring4.from_host(np.random.default_rng(99 + rank).integers(0, 5, size=(16, n4, 2), dtype=np.int32))
@@ -553,7 +611,8 @@ def worker_body(args, rdzv, overlap, note):
             el4.append(time.perf_counter() - t0)
             barrier()
             st4.append(env4.stats()["env_steps"] - s0)
-        cfg4_every = [json.loads(b) for b in rdzv.all_gather(json.dumps({"elapsed_s": el4, "env_steps": st4, "kernel_us": [0.0] * R4}).encode())]
+        cfg4_every = [json.loads(b) for b in rdzv.all_gather(json.dumps({"elapsed_s": el4, "env_steps": st4, "kernel_us": [0.0] * R4,
+                                                                         "env_id_base": base4, "envs": n4}).encode())]
         b_alg4 = algorithmic_bytes_per_env_step(env4)
         env4.close()
 
@@ -592,26 +651,11 @@ def worker_body(args, rdzv, overlap, note):
             if L.cz_probe_output_only(h, d_obs.ptr, N * 2 * env.F * 8, 500, C.byref(us)) == 0:
                 out_only_us = float(us.value)
         # secondary figure: the same work fused, T steps per launch with the on-device action stream and a trajectory buffer
-        fused = None
-        if not args.no_obs:
-            T = 32
-            d_traj = env.alloc((T, N, 2, env.F), np.float64)
-            d_r = env.alloc((T, N, 2), np.float64)
-            d_te = env.alloc((T, N, 2), np.uint8)
-            d_tr = env.alloc((T, N, 2), np.uint8)
-            reps = max(2, min(K, 2000) // T)
-            env.rollout(T, 1, 0, d_traj, d_r, d_te, d_tr)
-            env.sync()
-            f0 = env.stats()["env_steps"]
-            t0 = time.perf_counter()
-            for r in range(reps):
-                env.rollout(T, 1, (r + 1) * T, d_traj, d_r, d_te, d_tr)
-            env.sync()
-            dtf = time.perf_counter() - t0
-            fused = {"env_steps_per_s_per_gpu": (env.stats()["env_steps"] - f0) / dtf, "steps_per_launch": T,
-                     "ms_per_step": dtf * 1e3 / (reps * T), "api": "cz_rollout, obs trajectory [T][N][A][F] in HBM"}
-            for b in (d_traj, d_r, d_te, d_tr):
-                b.free()
+        fused = None if args.no_obs else guarded(leg_fused, env, K)
+        if fused is not None and "error" in fused:
+            line_fused_error, fused = fused, None
+        else:
+            line_fused_error = None
         rccl_path, hip_path = C.create_string_buffer(512), C.create_string_buffer(512)
         L.cz_runtime_paths(rccl_path, hip_path, 512)
         b_alg = algorithmic_bytes_per_env_step(env)
@@ -664,23 +708,22 @@ def worker_body(args, rdzv, overlap, note):
         }
         if note:
             line["overlap_fallback"] = note
+        if line_fused_error is not None:
+            line["fused_rollout"] = line_fused_error
         if fused is not None:
             line["fused_rollout"] = fused
             fused["roofline"] = roofline_block(b_alg, N, fused["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,true> (32 steps per launch)",
                                                "wall clock around the cz_rollout launches")
         if cfg4_every is not None:
-            a4 = aggregate(cfg4_every, 100)
-            line["config4"] = {"workload": f"BASELINE config 4 shape: 32768 envs per GPU x {world} GPU(s) = {32768 * world} envs, coop_test, 2 agents, global env ids, "
-                                           f"statistics all-gather over RCCL; one launch per step (graph replay), 100-step regions between all-rank barriers",
-                               "value": a4["value"], "unit": "env-steps/s", "ms_per_step": a4["ms_per_step"], "value_min": a4["value_min"], "value_max": a4["value_max"],
-                               "roofline": roofline_block(b_alg4, 32768, a4["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,false>", "wall clock of the slowest rank per region")}
+            line["config4"] = config4_block(world, cfg4_every, b_alg4)
         if world == 1 and not args.no_extras and not args.no_obs:
-            # what users get beside the open-loop headline; each leg a fraction of a second of GPU time
-            line["closed_loop"] = leg_closed_loop(env, d_obs, d_rew, d_term, d_trunc)
-            line["cooking_policy"] = leg_cooking_policy(local_rank)
-            line["configs"] = leg_configs(local_rank)
+            # what users get beside the open-loop headline; each leg a fraction of a second of GPU time.
+            # An extra leg must never be able to lose the headline measured above: whatever it raises is recorded under its key.
+            line["closed_loop"] = guarded(leg_closed_loop, env, d_obs, d_rew, d_term, d_trunc)
+            line["cooking_policy"] = guarded(leg_cooking_policy, local_rank)
+            line["configs"] = guarded(leg_configs, local_rank)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(env)
+            line["cpu_baseline"] = guarded(cpu_baseline, env)
         emit(line)
     try:
         rdzv.close()

@@ -167,7 +167,7 @@ struct cz_handle_s {
     bool copy_pending = false;             // a copy has been issued that no cz_set_layout_group has waited for yet
     struct SlotRange { int32_t first, count; };
     std::vector<SlotRange> upd_ranges;     // staged by cz_update_layouts, not copied yet (flush_updates)
-    std::vector<SlotRange> staged_on_copy, staged_on_main;   // the slots of the latest copy issued on the copy stream / in order on the handle's stream
+    std::vector<SlotRange> staged_on_copy, staged_on_main;   // slots of copies issued on the copy stream / in order on the handle's stream whose completion nobody has seen yet
     hipEvent_t ev_main_copy_done = nullptr;
     int32_t lay_groups = 1, lay_active = 0;
     int64_t n_layout_updates = 0;
@@ -739,13 +739,19 @@ static int flush_updates(cz_handle h, bool force) {
                                  hipMemcpyHostToDevice, st));
     }
     // (who reads which part of the staging block until when: cz_update_layouts waits before it rewrites the same slots)
+    // (the events are re-recorded behind ALL copies issued so far on their stream, so the lists only grow until somebody has
+    // waited for the event - cz_update_layouts before it rewrites staged slots - or found it complete)
     if (st == h->copy_stream) {
+        if (!h->staged_on_copy.empty() && hipEventQuery(h->ev_copy_done) == hipSuccess) h->staged_on_copy.clear();
+        (void)hipGetLastError();
         HIPCHK(h, hipEventRecord(h->ev_copy_done, h->copy_stream));
         h->copy_pending = true;
-        h->staged_on_copy = h->upd_ranges;
+        h->staged_on_copy.insert(h->staged_on_copy.end(), h->upd_ranges.begin(), h->upd_ranges.end());
     } else {
+        if (!h->staged_on_main.empty() && hipEventQuery(h->ev_main_copy_done) == hipSuccess) h->staged_on_main.clear();
+        (void)hipGetLastError();
         HIPCHK(h, hipEventRecord(h->ev_main_copy_done, h->stream));
-        h->staged_on_main = h->upd_ranges;
+        h->staged_on_main.insert(h->staged_on_main.end(), h->upd_ranges.begin(), h->upd_ranges.end());
     }
     h->upd_ranges.clear();
     return 0;
@@ -836,6 +842,10 @@ extern "C" int cz_set_state(cz_handle h, int64_t b, int64_t c, const uint32_t *r
                 return fail(h, "cz_set_state: record %lld: recipe id %u out of range", (long long)i, (r[W_RECIPES] >> (8 * k)) & 0xFFu);
         const uint32_t base = r[W_POOL] & 0xFFFFu, count = r[W_POOL] >> 16;
         if (count && h->n_layouts > 0 && (int)(base + count) > h->n_layouts) return fail(h, "cz_set_state: record %lld: layout pool slice out of range", (long long)i);
+        // a slot that is not alive carries no container tag: the kernels take "tagged" to imply "alive" (Ops::content_of)
+        for (int s2 = 0; s2 < h->P.D; ++s2)
+            if (!(r[h->P.dyn0_off + s2] & D_ALIVE) && (r[h->P.dyn1_off + s2] & 0xFFu))
+                return fail(h, "cz_set_state: record %lld: slot %d is not alive but carries a container tag", (long long)i, s2);
     }
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (b == 0 && c == h->P.N) { if (chain_recover(h)) return 1; }
@@ -862,19 +872,19 @@ static int ready(cz_handle h) {
     return 0;
 }
 
-static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr) {
+static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr, bool fused = false) {
     if (chain_failed(h, "step launch")) return 1;
     if (!stream) stream = h->stream;
     // write-through observation stores pay when the launch is short enough for the end-of-kernel L2 write-back to be
     // exposed: one step of a moderate batch; streaming stores when one launch's observations do not fit the memory-side
     // cache (256 MiB) any more.  (CZ_WT=0/1/2 overrides, for experiments.)
     const size_t obs_bytes = (size_t)P.N * P.A * P.F * 8;
-    if (P.actions) P.wt = obs_bytes <= ((size_t)128 << 20) ? 1 : obs_bytes > ((size_t)224 << 20) ? 2 : 0;
+    if (!fused) P.wt = obs_bytes <= ((size_t)128 << 20) ? 1 : obs_bytes > ((size_t)224 << 20) ? 2 : 0;
     // (fused: streaming stores only when an agent's row fills whole DRAM pages - 4 KiB and more, config 5: +8 %; with the
     // 2.2 KB rows of the 7x7 levels they lose 15 % against the cache's own write-back order, profiles/r03/wt_ab2.txt)
     else P.wt = (obs_bytes > ((size_t)224 << 20) && (size_t)P.F * 8 >= 4096) ? 2 : 0;
     if (h->wt_override >= 0) P.wt = h->wt_override;
-    if (P.actions) {          // the one-step kernels store rewards and flags unconditionally
+    if (!fused) {             // the one-step kernels store rewards and flags unconditionally
         if (!P.rewards) P.rewards = (double *)h->d_dump;
         if (!P.term) P.term = (uint8_t *)h->d_dump;
         if (!P.trunc) P.trunc = (uint8_t *)h->d_dump;
@@ -893,7 +903,7 @@ static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr) {
         h->kev_used += 2;
         HIPCHK(h, hipEventRecord(e0, stream));
     }
-    HIPCHK(h, h->kl.step(P, stream));
+    HIPCHK(h, h->kl.step(P, stream, fused));
     if (h->ktime) HIPCHK(h, hipEventRecord(e1, stream));
     return 0;
 }
@@ -1224,7 +1234,26 @@ extern "C" int cz_rollout(cz_handle h, int32_t T, uint64_t seed, uint32_t step0,
     Params P = h->P;
     P.actions = nullptr; P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc;
     P.T = T; P.seed = seed; P.step0 = step0;
-    return launch_step(h, P);
+    return launch_step(h, P, nullptr, true);
+}
+
+// The same fused launch over actions of the caller: d_actions int32 [T][N][A], step t of env e reads row t.  What replay and
+// open-loop search use instead of T one-step launches: the record stays in registers, every step's outputs land in the
+// trajectory buffers, and nothing has to be ordered between launches (so no overlapped mode is needed for it either).
+extern "C" int cz_rollout_actions(cz_handle h, int32_t T, const int32_t *d_actions, double *d_obs, double *d_rewards,
+                                  uint8_t *d_term, uint8_t *d_trunc) {
+    if (ready(h)) return 1;
+    if (T < 1 || !d_actions) return fail(h, "cz_rollout_actions: T must be >= 1 and the actions pointer non-null");
+    // (the kernel addresses rewards / flags / actions with 32-bit offsets from the array base)
+    if ((uint64_t)T * (uint64_t)h->P.N * (uint64_t)h->P.A * 8ull > 0xFFFFFFFFull)
+        return fail(h, "cz_rollout_actions: T * num_envs * num_agents * 8 must stay below 4 GiB (T <= %llu here): split the rollout",
+                    (unsigned long long)(0xFFFFFFFFull / ((uint64_t)h->P.N * h->P.A * 8ull)));
+    if (set_device(h)) return 1;
+    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
+    Params P = h->P;
+    P.actions = d_actions; P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc;
+    P.T = T; P.seed = 0; P.step0 = 0;
+    return launch_step(h, P, nullptr, true);
 }
 
 // the device address of pinned, device-mapped host memory (cz_host_alloc, hipHostMalloc, hipHostRegister); nullptr for

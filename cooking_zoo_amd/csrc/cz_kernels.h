@@ -677,6 +677,11 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     CZ_STAMP(1);
 
     const int T = FUSED ? P.T : 1;
+    // a fused rollout over caller-supplied actions (cz_rollout_actions: [T][N][A] int32): step t's action words are loaded one
+    // step ahead, so the round trip hides behind the previous step's work
+    const bool ext_actions = FUSED && e_actions != nullptr;
+    const uint32_t act_lane = ((uint32_t)env * (uint32_t)NA + (uint32_t)min(lane, NA - 1)) * 4u, act_step = (uint32_t)P.N * (uint32_t)NA * 4u;
+    if (FUSED && ext_actions) av = ldg<int>(e_actions, act_lane);
 #pragma nounroll
     for (int t = 0; t < T; ++t) {
         // The fused kernel re-reads its argument block every step (scalar loads that hit the constant cache): nothing of
@@ -698,7 +703,11 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         }
         uint32_t acts;                                             // lane a = action of agent a
         if (!FUSED) acts = (uint32_t)av;
-        else acts = action_hash(Pt.seed, env_global, lane & 3, Pt.step0 + (uint32_t)t, SCHEME == 3 ? 5u : 8u);
+        else if (ext_actions) {
+            acts = (uint32_t)av;
+            // (cz_rollout_actions checks that T * N * A * 4 fits 32 bits; the last step re-reads its own row)
+            av = ldg<int>(e_actions, act_lane + (uint32_t)min(t + 1, T - 1) * act_step);
+        } else acts = action_hash(Pt.seed, env_global, lane & 3, Pt.step0 + (uint32_t)t, SCHEME == 3 ? 5u : 8u);
         Dirty dt{};
         StepOut o;
         step_env<OPL, CPL, NA, SCHEME>(Pt, (unsigned)offsetof(StepArgsMirror, p), e, cx, acts, env_global, rowv, lds, dsc, dt, o);
@@ -894,7 +903,7 @@ __global__ __launch_bounds__(64) void k_observe(const Params P, int64_t env_begi
 
 // launchers exported by each instantiation unit
 struct Launchers {
-    hipError_t (*step)(const Params &, hipStream_t);
+    hipError_t (*step)(const Params &, hipStream_t, bool fused);      // fused: P.T steps per launch (actions: P.actions, or the on-device stream when null)
     hipError_t (*reset)(const Params &, hipStream_t, int64_t, int, const int32_t *, const uint32_t *, const uint32_t *, double *);
     hipError_t (*observe)(const Params &, hipStream_t, int64_t, int, double *);
     // how many envs of the overlapped one-step kernel (P.A agents, P.scheme) can be resident on the device at once
@@ -924,7 +933,7 @@ struct Inst {
         }
     }
     template <int NA>
-    static hipError_t step_na(const Params &P, hipStream_t st) {
+    static hipError_t step_na(const Params &P, hipStream_t st, bool fused) {
         constexpr int EPW = envs_per_wg<CPL>();
         const dim3 grid((unsigned)((P.N + EPW - 1) / EPW)), block(64 * EPW);
         const Early E = early_of(P);
@@ -932,30 +941,32 @@ struct Inst {
     hipLaunchKernelGGL((k_step<OPL, CPL, NA, S, F>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, P)
 #define CZ_LAUNCH_CHAIN(S) \
     hipLaunchKernelGGL((k_step_chain<OPL, CPL, NA, S>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, E.seq, P)
-        if (P.actions && (P.seq & SEQ_PUBLISH)) {
+        if (fused) {
+            if (P.scheme == 3) CZ_LAUNCH_STEP(3, true);
+            else CZ_LAUNCH_STEP(1, true);
+        } else if (!P.actions) {
+            return hipErrorInvalidValue;
+        } else if (P.seq & SEQ_PUBLISH) {
             if constexpr (chain_instance<OPL, CPL, NA>()) {
                 if (P.scheme == 3) CZ_LAUNCH_CHAIN(3);
                 else CZ_LAUNCH_CHAIN(1);
             } else {
                 return hipErrorInvalidValue;               // (cz_overlap_limit is 0 for this instance: the host never asks)
             }
-        } else if (P.actions) {
+        } else {
             if (P.scheme == 3) CZ_LAUNCH_STEP(3, false);
             else CZ_LAUNCH_STEP(1, false);
-        } else {
-            if (P.scheme == 3) CZ_LAUNCH_STEP(3, true);
-            else CZ_LAUNCH_STEP(1, true);
         }
 #undef CZ_LAUNCH_STEP
 #undef CZ_LAUNCH_CHAIN
         return hipGetLastError();
     }
-    static hipError_t step(const Params &P, hipStream_t st) {
+    static hipError_t step(const Params &P, hipStream_t st, bool fused) {
         switch (P.A) {
-        case 1: return step_na<1>(P, st);
-        case 2: return step_na<2>(P, st);
-        case 3: return step_na<3>(P, st);
-        default: return step_na<4>(P, st);
+        case 1: return step_na<1>(P, st, fused);
+        case 2: return step_na<2>(P, st, fused);
+        case 3: return step_na<3>(P, st, fused);
+        default: return step_na<4>(P, st, fused);
         }
     }
     static hipError_t reset(const Params &P, hipStream_t st, int64_t b, int n, const int32_t *lay, const uint32_t *rec,

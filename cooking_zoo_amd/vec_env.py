@@ -26,13 +26,14 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def _produce_layouts(q, stop, level_objects, meta, num_agents, dims_tuple, pool_slices, groups, seed):
-    """Body of the layout-rotation process (CookingVecEnv.rotate_layouts): batch b refills part b % groups of every level's
-    pool slice; its layouts come from random.Random streams keyed by (seed, b, level), so a run can be replayed."""
+def _produce_layouts(q, stop, level_objects, meta, num_agents, dims_tuple, pool_slices, groups, seed, start=0):
+    """Body of the layout-rotation process (CookingVecEnv.rotate_layouts): batch b refills part (start + b) % groups of every
+    level's pool slice (`start` = the part the envs drew from when the rotation began: the first one to be retired); its
+    layouts come from random.Random streams keyed by (seed, b, level), so a run can be replayed."""
     dims = soa.Dims(*dims_tuple)
     b = 0
     while not stop.is_set():
-        g = b % groups
+        g = (start + b) % groups
         batch = []
         for li, lv in enumerate(level_objects):
             base, count = pool_slices[li]
@@ -292,8 +293,9 @@ class CookingVecEnv:
         if every < self.max_steps + 3:
             raise ValueError("`every` must be at least max_steps + 3 steps: a part is refilled max_steps + 2 steps after the "
                              "envs stopped drawing from it, and before they draw from it again")
+        start = self._lay_active if self._lay_groups == groups else 0        # the part in use now: the first one to be refilled
         rot = {"groups": int(groups), "every": int(every), "flip_due": self._steps + int(every), "refill_due": None, "n_refills": 0,
-               "blocking": bool(blocking)}
+               "blocking": bool(blocking), "start": int(start)}
 
         # The instantiation is plain Python (engine/load_level.py, the reference's draw order) and takes milliseconds per batch:
         # in a thread it would hold the interpreter lock against the thread that issues the steps, so it runs in a process of
@@ -304,7 +306,7 @@ class CookingVecEnv:
         rot["stop"] = ctx.Event()
         rot["process"] = ctx.Process(target=_produce_layouts, name="cz-layout-rotation", daemon=True,
                                      args=(rot["queue"], rot["stop"], self.level_objects, self.meta, self.num_agents, self.dims.as_tuple(),
-                                           list(self.pool_slices), int(groups), int(seed)))
+                                           list(self.pool_slices), int(groups), int(seed), int(start)))
         # ... and a small thread takes the batches off the process queue (unpickling costs a millisecond) into a local one
         rot["ready"] = _queue.Queue(maxsize=max(1, int(prefetch)))        # (bounded: when it is full everything upstream sleeps)
 
@@ -324,7 +326,7 @@ class CookingVecEnv:
         rot["drain"] = _threading.Thread(target=drain, name="cz-layout-rotation-drain", daemon=True)
         self._rot = rot
         _native.check(self._h, _native.lib().cz_update_layouts(self._h, 0, 0, None, None))     # copy stream + staging, ahead of time
-        self.set_layout_group(groups, self._lay_active if self._lay_groups == groups else 0)
+        self.set_layout_group(groups, start)
         rot["process"].start()
         rot["drain"].start()
 
@@ -342,6 +344,14 @@ class CookingVecEnv:
             if rot["process"].is_alive():
                 rot["process"].terminate()
 
+    @staticmethod
+    def _rotation_pending(rot):
+        """a batch still on its way from the producer's queue to the local one"""
+        try:
+            return not rot["queue"].empty()
+        except (OSError, ValueError):
+            return False
+
     def rotation_ready(self):
         """refills the background process has ready right now (a measurement may want to start with a full queue)"""
         return 0 if self._rot is None else self._rot["ready"].qsize()
@@ -353,18 +363,32 @@ class CookingVecEnv:
         if rot is None:
             return
         if rot["refill_due"] is not None and self._steps >= rot["refill_due"]:
-            try:
-                batch = rot["ready"].get(block=rot["blocking"])            # (blocking: waits for the producer if it is behind)
-            except _queue.Empty:
-                return                                                      # not ready: next call
+            batch = None
+            while batch is None:
+                try:
+                    # (blocking: waits for the producer if it is behind - in slices, so that a producer that died is noticed)
+                    batch = rot["ready"].get(timeout=0.25) if rot["blocking"] else rot["ready"].get_nowait()
+                except _queue.Empty:
+                    dead = not rot["process"].is_alive() and rot["ready"].empty() and not self._rotation_pending(rot)
+                    rot["dead_polls"] = rot.get("dead_polls", 0) + 1 if dead else 0   # (twice in a row: a batch may be in the drain thread's hands)
+                    if rot["dead_polls"] >= 2:
+                        code = rot["process"].exitcode
+                        self.stop_rotation()
+                        raise RuntimeError(f"rotate_layouts: the layout producer process died (exit code {code}); rotation stopped, "
+                                           f"the envs keep drawing from part {self._lay_active} of {self._lay_groups}")
+                    if not rot["blocking"]:
+                        return                                              # not ready: next call
             for first, lays, recs, desc in batch:
                 self._update_layout_arrays(first, lays, recs, desc)
             rot["refill_due"] = None
             rot["n_refills"] += 1
         if rot["refill_due"] is None and self._steps >= rot["flip_due"]:
             old = self._lay_active
+            if old != (rot["start"] + rot["n_refills"]) % rot["groups"]:      # the part the producer's next batch is made for
+                self.stop_rotation()
+                raise RuntimeError("rotate_layouts: the active layout group was changed behind the rotation's back "
+                                   "(set_layout_group while rotate_layouts runs); rotation stopped")
             self.set_layout_group(rot["groups"], (old + 1) % rot["groups"])
-            assert old == rot["n_refills"] % rot["groups"]                    # the part the producer's next batch is made for
             rot["refill_due"] = self._steps + self.max_steps + 2
             rot["flip_due"] = self._steps + rot["every"]
 
@@ -495,6 +519,14 @@ class CookingVecEnv:
         p = _dev_ptr
         _native.check(self._h, _native.lib().cz_rollout(self._h, int(T), int(seed), int(step0), p(d_obs), p(d_rewards),
                                                         p(d_term), p(d_trunc)))
+        self._advance(T)
+
+    def rollout_actions(self, d_actions, T, d_obs=None, d_rewards=None, d_term=None, d_trunc=None):
+        """T fused steps over the caller's actions (device int32 [T, N, A]); every step's outputs go to the trajectory
+        buffers ([T, N, A, F] / [T, N, A]).  Same results as T `step_device` calls over those rows."""
+        p = _dev_ptr
+        _native.check(self._h, _native.lib().cz_rollout_actions(self._h, int(T), p(d_actions), p(d_obs), p(d_rewards),
+                                                                p(d_term), p(d_trunc)))
         self._advance(T)
 
     def sync(self):

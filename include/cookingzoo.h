@@ -222,6 +222,12 @@ int cz_chain_counts(cz_handle h, int64_t *chained_kernels, int32_t reset);
 int cz_rollout(cz_handle h, int32_t T, uint64_t seed, uint32_t step0, double *d_obs, double *d_rewards,
                uint8_t *d_terminations, uint8_t *d_truncations);
 
+/* The same fused launch over actions of the caller (replay, open-loop search): d_actions int32 [T][N][A], step t reads row t
+ * (values as for cz_step_device: action & 7, negative = the agent does not act).  Same results as T cz_step_device launches
+ * over those rows, with every step's outputs in the trajectory buffers. */
+int cz_rollout_actions(cz_handle h, int32_t T, const int32_t *d_actions, double *d_obs, double *d_rewards,
+                       uint8_t *d_terminations, uint8_t *d_truncations);
+
 /* the action the on-device stream draws (host mirror, for parity tests) */
 uint32_t cz_action(uint64_t seed, int64_t env_global, int32_t agent, uint32_t step, uint32_t n_actions);
 /* the layout an env draws for its k-th episode under auto_reset */

@@ -154,3 +154,33 @@ def test_launcher_interrupted_kills_its_ranks(tmp_path):
         except (ProcessLookupError, FileNotFoundError):
             gone = True
         assert gone, f"rank process {pid} survived its launcher"
+
+
+def test_eight_ranks_dry_run_has_config4_and_one_device_per_rank():
+    """First-contact insurance for the round-end 8-GPU run (no hardware needed): `bench.py --gpus 8 --dry-run` through
+    launch_local - eight fresh rank processes, rendezvous, aggregation - gives one line with n_gpus 8, BASELINE config 4
+    (262 144 envs) cut into eight contiguous shards of 32 768 global env ids, and every rank on the device LOCAL_RANK names."""
+    p = _run_bench("--gpus", "8", "--dry-run", "--steps", "20", "--warmup", "5", "--repeats", "3", "--envs", "4096")
+    assert p.returncode == 0, p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak"
+    assert d["device_ids"] == list(range(8))                       # rank r drives device LOCAL_RANK = r, nobody shares one
+    assert d["shards"] == [[4096 * r, 4096] for r in range(8)] and d["env_id_bases"] == [4096 * r for r in range(8)]
+    c4 = d["config4"]
+    assert c4["envs"] == 262144 and "262144 envs" in c4["workload"]
+    assert c4["shards"] == [[32768 * r, 32768] for r in range(8)]
+    covered = sorted((b, b + n) for b, n in c4["shards"])
+    assert covered[0][0] == 0 and covered[-1][1] == 262144 and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    # whole-job value: all ranks' env-steps over the slowest rank's time (dry-run: rank r's region takes 1e-2 (r + 1) s)
+    assert c4["value"] == pytest.approx(8 * 100 * 32768 / (1e-2 * 8))
+
+
+def test_gpus_1_equals_the_plain_run():
+    """`--gpus 1` (launcher-less single rank) and a plain run are the same code path: same line but for the timings"""
+    a = _run_bench("--gpus", "1", "--dry-run", "--steps", "8", "--warmup", "0", "--repeats", "4", "--envs", "16")
+    b = _run_bench("--dry-run", "--steps", "8", "--warmup", "0", "--repeats", "4", "--envs", "16")
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+    da, db = (json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0]) for p in (a, b))
+    assert da == db and da["value"] == pytest.approx(db["value"]) and da["device_ids"] == [0] and "config4" not in da
