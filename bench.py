@@ -190,7 +190,7 @@ def leg_closed_loop(env, d_obs, d_rew, d_term, d_trunc):
     return {"env_steps_per_s": stepped * N / (us.value * 1e-6), "us_per_step": us.value, "envs": N,
             "what": "closed loop on one stream: cz_step_device -> policy kernel (next actions = hash of the observation just written) "
                     f"-> cz_step_device ...; {K}-step HIP graph replayed {reps} times, HIP events; includes the policy kernel and its launch boundary",
-            "roofline": roofline_block(b_alg, N, us.value, "cz::k_step<1,1,2,3,false> + k_probe_policy per step",
+            "roofline": roofline_block(b_alg, N, us.value, "cz::k_step<1,1,2,3,0> + k_probe_policy per step",
                                        "HIP events around graph replays of the closed loop; step + policy kernel + both boundaries")}
 
 
@@ -264,7 +264,7 @@ def leg_cooking_policy(device_id):
            "return_sum_agent0": st["return_sum"][0],
            "what": f"one launch per step, launch-boundary ordering (graph replay); every env replays the reference heuristic agent's actions "
                    f"(golden fixtures cfg2_coop_2agents: {P} episodes of {min(T)}-{max(T)} steps that chop, plate and deliver) from its own phase",
-           "roofline": roofline_block(b_alg, N, us, "cz::k_step<1,1,2,3,false>", "HIP events around one graph-replayed run of 512 launches")}
+           "roofline": roofline_block(b_alg, N, us, "cz::k_step<1,1,2,3,0>", "HIP events around one graph-replayed run of 512 launches")}
     env.close()
     return out
 
@@ -342,7 +342,7 @@ def config4_block(world, per_rank, b_alg4):
            "envs": total, "shards": [[p["env_id_base"], p["envs"]] for p in per_rank],
            "value": a4["value"], "unit": "env-steps/s", "ms_per_step": a4["ms_per_step"], "value_min": a4["value_min"], "value_max": a4["value_max"]}
     if b_alg4 is not None:
-        out["roofline"] = roofline_block(b_alg4, CFG4_ENVS_PER_GPU, a4["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,false>", "wall clock of the slowest rank per region")
+        out["roofline"] = roofline_block(b_alg4, CFG4_ENVS_PER_GPU, a4["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,0>", "wall clock of the slowest rank per region")
     return out
 
 
@@ -680,13 +680,13 @@ def worker_body(args, rdzv, overlap, note):
                                   "actions resident in HBM, device-resident outputs",
                        "envs_per_gpu": N, "parallelism": f"env-sharded x{world}, one wavefront per env, one process per GPU, no torch",
                        "api": api},
-            # The dominant kernel's roofline is quoted from the launch-boundary-ordered kernel, cz::k_step<1,1,2,3,false>: its HIP-event
+            # The dominant kernel's roofline is quoted from the launch-boundary-ordered kernel, cz::k_step<1,1,2,3,0>: its HIP-event
             # launch duration agrees with rocprofv3's per-kernel average for that kernel (profiles/r03/kernel_stats_ordered.csv).  When
             # the timed regions ran as overlapped launches, the launch-to-launch interval of those is given next to it, with
             # the device-clock timeline that shows it (a per-kernel trace cannot: two of those kernels are resident at a time).
             "roofline": {"bound": "hbm", "achieved": b_alg * N / (kernel_us[1] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": b_alg * N / (kernel_us[1] * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(f"k_step_{N}"),
-                         "kernel": "cz::k_step<1,1,2,3,false> (one wavefront per env, 8 envs per workgroup)",
+                         "kernel": "cz::k_step<1,1,2,3,0> (one wavefront per env, 8 envs per workgroup)",
                          "kernel_us": kernel_us[1],
                          "kernel_us_from": (f"HIP events on the kernels' stream around {max(R * K, 4000)} launches issued back to back (graph replay, "
                                             f"ordered by launch boundaries), divided by the number of launches; rocprofv3 --kernel-trace of the same "
@@ -712,7 +712,7 @@ def worker_body(args, rdzv, overlap, note):
             line["fused_rollout"] = line_fused_error
         if fused is not None:
             line["fused_rollout"] = fused
-            fused["roofline"] = roofline_block(b_alg, N, fused["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,true> (32 steps per launch)",
+            fused["roofline"] = roofline_block(b_alg, N, fused["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,1> (32 steps per launch)",
                                                "wall clock around the cz_rollout launches")
         if cfg4_every is not None:
             line["config4"] = config4_block(world, cfg4_every, b_alg4)

@@ -260,6 +260,12 @@ __device__ __forceinline__ void load_desc(const Params &P, uint32_t layout, int 
     }
 }
 
+// the axis-code field of a descriptor word (bits 16..23: code * 4).  Bit 31 is the library's own mark (cz_load_layouts /
+// cz_update_layouts set it, callers never do): this feature PAIR depends on an object or on a mutable cell flag, i.e. on more
+// than the agents' final positions - the two-waves-per-env kernel (cz_duo.h) encodes those pairs late, the others early.
+__device__ __forceinline__ uint32_t desc_code(uint32_t w) { return __builtin_amdgcn_ubfe(w, 16, 8); }
+constexpr uint32_t DESC_LATE = 1u << 31;
+
 // cooking_env.py:352-373 get_feature_vector for every agent of the env: out[a][f] = lut[img[desc.hw] - sub[a][desc.code]]
 // P.wt selects the cache policy of the observation stores (wave-uniform; policy in cz_api.hip launch_step):
 //   1 = write-through (`buffer_store_dwordx4 ... sc1`): the bytes leave the XCD's L2 while the kernel still computes instead
@@ -345,7 +351,7 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
-            for (int j = 0; j < OBS_CHUNK; ++j) sb[a][j] = *reinterpret_cast<const int32_t *>(subb + 64 * a + (dsc[j] >> 16));
+            for (int j = 0; j < OBS_CHUNK; ++j) sb[a][j] = *reinterpret_cast<const int32_t *>(subb + 64 * a + desc_code(dsc[j]));
         double2_t v[NA][OBS_PAIRS];
 #pragma unroll
         for (int a = 0; a < NA; ++a)
@@ -378,9 +384,14 @@ struct StepOut {
 };
 
 // One accumulated_step (cooking_env.py:243-269) of one env held in registers.
-template <int OPL, int CPL, int NA, int SCHEME>
+// `agents_final` is called once, at the point from which the agents' positions and orientations no longer change in this pass
+// (after the walking half of perform_agent_actions; after handle_agent_spawn when despawn / respawn is on; after a reset):
+// the two-waves-per-env kernel (cz_duo.h) publishes the agent words to its helper wave there; everybody else passes nothing.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int OPL, int CPL, int NA, int SCHEME, class Hook = NoHook>
 __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t acts,
-                                         int64_t env_global, uint32_t &rowv, Lds<CPL> &lds, uint32_t (&dsc)[OBS_CHUNK], Dirty &dt, StepOut &o) {
+                                         int64_t env_global, uint32_t &rowv, Lds<CPL> &lds, uint32_t (&dsc)[OBS_CHUNK], Dirty &dt, StepOut &o,
+                                         Hook agents_final = Hook{}) {
     using O = Ops<OPL, CPL, NA, SCHEME>;
     o.myrew = 0.0;
     o.term = 0; o.trunc = 0; o.stepped = false; o.finished = false; o.header = false; o.gone = 0u;
@@ -411,6 +422,7 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
             o.term = (e.status & ST_TERM) ? 1u : 0u;
             o.trunc = (e.status & ST_TRUNC) ? 1u : 0u;
         }
+        agents_final();
         return;
     }
     o.stepped = true;
@@ -420,12 +432,17 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
 #if defined(CZ_PROFILE)
     const int lane = cx.lane; const long long env = env_global - P.env_id_base;
 #endif
-    O::perform_agent_actions(e, cx, acts, dt);                      // cooking_world.py:104-108
+    {                                                               // cooking_world.py:104-108 perform_agent_actions
+        const typename O::Pre pre = O::agents_walk(e, cx, acts, dt);
+        if (!spawning) agents_final();
+        O::agents_interact(e, cx, pre, dt);
+    }
     CZ_STAMP(2);
     O::progress_and_link(e, cx, dt);
     if (spawning) {                             // :109-110 handle_agent_spawn
         o.gone = O::handle_agent_spawn(e, cx, spawn_cfg, env_global);
         o.header = true;                        // (the grace counters live in the status word)
+        agents_final();
     }
     CZ_STAMP(3);
     // compute_rewards cooking_env.py:290-315
@@ -559,7 +576,9 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
 }
 
 // ENVS_PER_WG envs per workgroup (one wavefront each, no cross-wave communication).
-// FUSED = false: one step, actions from memory.  FUSED = true: P.T steps, on-device action stream, outputs [t][env].
+// FUSED = 0: one step, actions from memory.  FUSED = 1: P.T steps, on-device action stream, outputs [t][env].  FUSED = 2: P.T
+// steps over the caller's actions [t][env][agent] (cz_rollout_actions; its own instance so that the on-device stream's loop
+// carries none of it: as a run-time branch it cost the random-action rollout 4 %).
 // What the very first loads of a wave need travels as leading scalar kernel arguments: the build preloads them into
 // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, gfx940+), so the record / action / table loads are issued
 // without waiting for an argument fetch; everything else stays in the by-value block `P0`, fetched meanwhile.
@@ -577,7 +596,7 @@ __host__ __device__ inline Early early_of(const Params &P) {
 // CHAIN = true: the one-step kernel of an overlapped run (SEQ_* in cz_device.h) -- its own kernel (k_step_chain below),
 // so that the ordinary kernel keeps its argument list and a prologue free of branches (a branch in front of the loads
 // costs 0.8 us per launch there)
-template <int OPL, int CPL, int NA, int SCHEME, bool FUSED, bool CHAIN>
+template <int OPL, int CPL, int NA, int SCHEME, int FUSED_MODE, bool CHAIN>
 __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
                                             int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
                                             int32_t e_dyn1, uint32_t e_seq, const Params &P0) {
@@ -609,6 +628,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     double *retp = reinterpret_cast<double *>(rec + RET_WORD0);
     // ---- an overlapped launch first waits for its env's predecessor (SEQ_* in cz_device.h); ordinary launches skip this
     uint32_t *const seqw = P.state + (size_t)P.N * P.RW + (size_t)env * SEQ_STRIDE_WORDS;
+    constexpr bool FUSED = FUSED_MODE != 0, EXT = FUSED_MODE == 2;
     static_assert(!(FUSED && CHAIN), "overlapped launches are one-step launches");
     constexpr bool chained = CHAIN;
     bool abandoned = false;
@@ -679,9 +699,8 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     const int T = FUSED ? P.T : 1;
     // a fused rollout over caller-supplied actions (cz_rollout_actions: [T][N][A] int32): step t's action words are loaded one
     // step ahead, so the round trip hides behind the previous step's work
-    const bool ext_actions = FUSED && e_actions != nullptr;
-    const uint32_t act_lane = ((uint32_t)env * (uint32_t)NA + (uint32_t)min(lane, NA - 1)) * 4u, act_step = (uint32_t)P.N * (uint32_t)NA * 4u;
-    if (FUSED && ext_actions) av = ldg<int>(e_actions, act_lane);
+    const uint32_t act_lane = ((uint32_t)env * (uint32_t)NA + (uint32_t)min(lane, NA - 1)) * 4u;
+    if (EXT) av = ldg<int>(e_actions, act_lane);
 #pragma nounroll
     for (int t = 0; t < T; ++t) {
         // The fused kernel re-reads its argument block every step (scalar loads that hit the constant cache): nothing of
@@ -703,10 +722,10 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         }
         uint32_t acts;                                             // lane a = action of agent a
         if (!FUSED) acts = (uint32_t)av;
-        else if (ext_actions) {
+        else if (EXT) {
             acts = (uint32_t)av;
             // (cz_rollout_actions checks that T * N * A * 4 fits 32 bits; the last step re-reads its own row)
-            av = ldg<int>(e_actions, act_lane + (uint32_t)min(t + 1, T - 1) * act_step);
+            av = ldg<int>(e_actions, act_lane + (uint32_t)min(t + 1, T - 1) * ((uint32_t)Pt.N * (uint32_t)NA * 4u));
         } else acts = action_hash(Pt.seed, env_global, lane & 3, Pt.step0 + (uint32_t)t, SCHEME == 3 ? 5u : 8u);
         Dirty dt{};
         StepOut o;
@@ -814,11 +833,11 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
 // waves - and forcing that one to six (80 registers, 3 spilled) changed nothing: 195 against 197 M env-steps/s,
 // profiles/r03/wpe_ab.txt)
 #ifdef CZ_STEP_MIN_WPE
-#define CZ_STEP_ATTR __attribute__((amdgpu_waves_per_eu((!FUSED && OPL <= 2) ? CZ_STEP_MIN_WPE : 1)))
+#define CZ_STEP_ATTR __attribute__((amdgpu_waves_per_eu((FUSED == 0 && OPL <= 2) ? CZ_STEP_MIN_WPE : 1)))
 #else
 #define CZ_STEP_ATTR
 #endif
-template <int OPL, int CPL, int NA, int SCHEME, bool FUSED>
+template <int OPL, int CPL, int NA, int SCHEME, int FUSED>
 __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) CZ_STEP_ATTR void k_step(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
                                                           int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
                                                           int32_t e_dyn1, const Params P0) {
@@ -848,8 +867,12 @@ template <int OPL, int CPL, int NA, int SCHEME>
 __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) CZ_CHAIN_ATTR void k_step_chain(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
                                                                 int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
                                                                 int32_t e_dyn1, uint32_t e_seq, const Params P0) {
-    step_kernel<OPL, CPL, NA, SCHEME, false, true>(e_state, e_actions, e_lut, e_N, e_RW, e_W, e_H, e_D, e_dyn0, e_dyn1, e_seq, P0);
+    step_kernel<OPL, CPL, NA, SCHEME, 0, true>(e_state, e_actions, e_lut, e_N, e_RW, e_W, e_H, e_D, e_dyn0, e_dyn1, e_seq, P0);
 }
+
+}  // namespace cz
+#include "cz_duo.h"
+namespace cz {
 
 // reset(): cooking_env.py:178-210 for envs [env_begin, env_begin + count)
 template <int OPL, int CPL, int NA>
@@ -902,8 +925,11 @@ __global__ __launch_bounds__(64) void k_observe(const Params P, int64_t env_begi
 }
 
 // launchers exported by each instantiation unit
+enum : int { LAUNCH_ONE = 0, LAUNCH_FUSED = 1, LAUNCH_DUO = 2 };
 struct Launchers {
-    hipError_t (*step)(const Params &, hipStream_t, bool fused);      // fused: P.T steps per launch (actions: P.actions, or the on-device stream when null)
+    // mode: LAUNCH_ONE = one step; LAUNCH_FUSED = P.T steps per launch (actions: P.actions, or the on-device stream when null);
+    // LAUNCH_DUO = one step with two wavefronts per env (cz_duo.h; instances without it launch the ordinary kernel)
+    hipError_t (*step)(const Params &, hipStream_t, int mode);
     hipError_t (*reset)(const Params &, hipStream_t, int64_t, int, const int32_t *, const uint32_t *, const uint32_t *, double *);
     hipError_t (*observe)(const Params &, hipStream_t, int64_t, int, double *);
     // how many envs of the overlapped one-step kernel (P.A agents, P.scheme) can be resident on the device at once
@@ -933,7 +959,8 @@ struct Inst {
         }
     }
     template <int NA>
-    static hipError_t step_na(const Params &P, hipStream_t st, bool fused) {
+    static hipError_t step_na(const Params &P, hipStream_t st, int mode) {
+        const bool fused = mode == LAUNCH_FUSED;
         constexpr int EPW = envs_per_wg<CPL>();
         const dim3 grid((unsigned)((P.N + EPW - 1) / EPW)), block(64 * EPW);
         const Early E = early_of(P);
@@ -941,11 +968,20 @@ struct Inst {
     hipLaunchKernelGGL((k_step<OPL, CPL, NA, S, F>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, P)
 #define CZ_LAUNCH_CHAIN(S) \
     hipLaunchKernelGGL((k_step_chain<OPL, CPL, NA, S>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, E.seq, P)
-        if (fused) {
-            if (P.scheme == 3) CZ_LAUNCH_STEP(3, true);
-            else CZ_LAUNCH_STEP(1, true);
+        if (fused && P.actions) {
+            if (P.scheme == 3) CZ_LAUNCH_STEP(3, 2);
+            else CZ_LAUNCH_STEP(1, 2);
+        } else if (fused) {
+            if (P.scheme == 3) CZ_LAUNCH_STEP(3, 1);
+            else CZ_LAUNCH_STEP(1, 1);
         } else if (!P.actions) {
             return hipErrorInvalidValue;
+        } else if (mode == LAUNCH_DUO && OPL == 1 && CPL == 1 && !(P.seq & SEQ_PUBLISH)) {
+            if constexpr (OPL == 1 && CPL == 1) {
+                const dim3 dgrid((unsigned)((P.N + DUO_EPW - 1) / DUO_EPW)), dblock(64 * 2 * DUO_EPW);
+                if (P.scheme == 3) hipLaunchKernelGGL((k_step_duo<NA, 3>), dgrid, dblock, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, P);
+                else hipLaunchKernelGGL((k_step_duo<NA, 1>), dgrid, dblock, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, P);
+            }
         } else if (P.seq & SEQ_PUBLISH) {
             if constexpr (chain_instance<OPL, CPL, NA>()) {
                 if (P.scheme == 3) CZ_LAUNCH_CHAIN(3);
@@ -954,19 +990,19 @@ struct Inst {
                 return hipErrorInvalidValue;               // (cz_overlap_limit is 0 for this instance: the host never asks)
             }
         } else {
-            if (P.scheme == 3) CZ_LAUNCH_STEP(3, false);
-            else CZ_LAUNCH_STEP(1, false);
+            if (P.scheme == 3) CZ_LAUNCH_STEP(3, 0);
+            else CZ_LAUNCH_STEP(1, 0);
         }
 #undef CZ_LAUNCH_STEP
 #undef CZ_LAUNCH_CHAIN
         return hipGetLastError();
     }
-    static hipError_t step(const Params &P, hipStream_t st, bool fused) {
+    static hipError_t step(const Params &P, hipStream_t st, int mode) {
         switch (P.A) {
-        case 1: return step_na<1>(P, st, fused);
-        case 2: return step_na<2>(P, st, fused);
-        case 3: return step_na<3>(P, st, fused);
-        default: return step_na<4>(P, st, fused);
+        case 1: return step_na<1>(P, st, mode);
+        case 2: return step_na<2>(P, st, mode);
+        case 3: return step_na<3>(P, st, mode);
+        default: return step_na<4>(P, st, mode);
         }
     }
     static hipError_t reset(const Params &P, hipStream_t st, int64_t b, int n, const int32_t *lay, const uint32_t *rec,
