@@ -216,7 +216,6 @@ struct cz_handle_s {
     unsigned long long *tl_base = nullptr;   // timeline build: stamp buffer, its capacity in launches, launches so far
     int32_t tl_cap = 0;
     int64_t tl_count = 0;
-    bool duo = false;              // CZ_DUO=1 (experiment): one-step launches of the small instance use two wavefronts per env (cz_duo.h)
     bool graphs_enabled = true;    // CZ_GRAPHS=0: cz_step_device_ring launches everything directly
     int32_t ring_prefix = 0;       // CZ_RING_PREFIX: steps of a cz_step_device_ring call launched directly in front of its first graph
     size_t zero_copy_bytes = (size_t)256 << 10;   // cz_step: batches whose buffers fit use the pinned device-mapped block (CZ_ZERO_COPY_BYTES)
@@ -286,8 +285,6 @@ extern "C" int cz_debug_set_timeline(cz_handle h, void *d_buf, int32_t cap_launc
     h->tl_base = (unsigned long long *)d_buf;
     h->tl_cap = d_buf ? cap_launches : 0;
     h->tl_count = 0;
-    if (d_buf && cap_launches > 0)       // (the two-waves-per-env kernel takes a maximum over its waves' exit stamps)
-        HIPCHK(h, hipMemsetAsync(d_buf, 0, (size_t)cap_launches * (size_t)h->P.N * 16, h->stream));
     return 0;
 #else
     (void)d_buf; (void)cap_launches;
@@ -364,7 +361,6 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     P.stop = -1;
     if (const char *s = getenv("CZ_WT")) h->wt_override = atoi(s);
     if (const char *s = getenv("CZ_GRAPHS")) h->graphs_enabled = atoi(s) != 0;
-    if (const char *s = getenv("CZ_DUO")) h->duo = atoi(s) != 0;
     h->chain_wanted_by_env = getenv("CZ_CHAIN") && atoi(getenv("CZ_CHAIN")) != 0;
     if (const char *s = getenv("CZ_RING_PREFIX")) h->ring_prefix = atoi(s) < 0 ? 0 : (atoi(s) > 16 ? 16 : atoi(s));
     if (const char *s = getenv("CZ_ZERO_COPY_BYTES")) h->zero_copy_bytes = (size_t)atoll(s);
@@ -684,28 +680,6 @@ static int validate_layouts(cz_handle h, const char *who, const uint32_t *init_r
     return 0;
 }
 
-// The library's own mark in the descriptor words it stores (bit 31, DESC_LATE): this feature pair - features 2k and 2k + 1 of a
-// row - reads an object's halfwords or a cell's mutable flag, i.e. depends on more than the agents' final positions.  The
-// two-waves-per-env kernel (cz_duo.h) encodes those pairs after the dynamics and everything else right after the walking.
-static void mark_late_pairs(cz_handle h, uint32_t *desc, size_t n_layouts) {
-    const uint32_t cell0 = h->huge ? Img<16>::CELL0 : Img<1>::CELL0, ag0 = h->huge ? Img<16>::AG0 : Img<1>::AG0;
-    auto late = [&](uint32_t w) {
-        const uint32_t hw = (w & 0xFFFFu) >> 1;
-        return hw < cell0 || (hw < ag0 && ((hw - cell0) & 3u) == 2u);
-    };
-    const size_t F = (size_t)h->P.F;
-    for (size_t l = 0; l < n_layouts; ++l) {
-        uint32_t *row = desc + l * F;
-        for (size_t f = 0; f < F; f += 2) {
-            const bool two = f + 1 < F;
-            if (late(row[f]) || (two && late(row[f + 1]))) {
-                row[f] |= DESC_LATE;
-                if (two) row[f + 1] |= DESC_LATE;
-            }
-        }
-    }
-}
-
 extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const uint32_t *obs_desc, int32_t n) {
     if (!h || !init_records || !obs_desc || n < 1 || n > 65535) return fail(h, "cz_load_layouts: bad arguments");
     if (validate_layouts(h, "cz_load_layouts", init_records, obs_desc, n)) return 1;
@@ -739,9 +713,7 @@ extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const 
     HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->d_lay_block + LC_GROUPS), 1, 1, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_lay_desc, 0, b1 + 16, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_lay_init, init_records, b0, hipMemcpyHostToDevice, h->stream));
-    std::vector<uint32_t> marked(obs_desc, obs_desc + (size_t)n * h->P.F);
-    mark_late_pairs(h, marked.data(), (size_t)n);
-    HIPCHK(h, hipMemcpyAsync(h->d_lay_desc, marked.data(), b1, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_lay_desc, obs_desc, b1, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->n_layouts = n;
     h->lay_groups = 1; h->lay_active = 0; h->upd_ranges.clear(); h->staged_on_copy.clear(); h->staged_on_main.clear(); h->copy_pending = false;
@@ -822,7 +794,6 @@ extern "C" int cz_update_layouts(cz_handle h, int32_t first, int32_t count, cons
     char *const st_rec = h->h_lay_stage + (size_t)first * RWb, *const st_desc = h->h_lay_stage + L * RWb + (size_t)first * Fb;
     memcpy(st_rec, init_records, (size_t)count * RWb);
     memcpy(st_desc, obs_desc, (size_t)count * Fb);
-    mark_late_pairs(h, (uint32_t *)st_desc, (size_t)count);
     // The copy must come after every step issued so far (their envs may still read the old content).  A device-side wait of the
     // copy stream for the handle's stream would do - and slow every step kernel down by a microsecond for as long as it is
     // pending (a second hardware queue with an outstanding barrier: measured, tools/rot_probe.py).  So the copy is issued
@@ -932,7 +903,7 @@ static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr, boo
         h->kev_used += 2;
         HIPCHK(h, hipEventRecord(e0, stream));
     }
-    HIPCHK(h, h->kl.step(P, stream, fused ? LAUNCH_FUSED : (h->duo && !(P.seq & SEQ_PUBLISH)) ? LAUNCH_DUO : LAUNCH_ONE));
+    HIPCHK(h, h->kl.step(P, stream, fused ? LAUNCH_FUSED : LAUNCH_ONE));
     if (h->ktime) HIPCHK(h, hipEventRecord(e1, stream));
     return 0;
 }

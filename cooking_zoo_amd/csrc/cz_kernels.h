@@ -260,12 +260,6 @@ __device__ __forceinline__ void load_desc(const Params &P, uint32_t layout, int 
     }
 }
 
-// the axis-code field of a descriptor word (bits 16..23: code * 4).  Bit 31 is the library's own mark (cz_load_layouts /
-// cz_update_layouts set it, callers never do): this feature PAIR depends on an object or on a mutable cell flag, i.e. on more
-// than the agents' final positions - the two-waves-per-env kernel (cz_duo.h) encodes those pairs late, the others early.
-__device__ __forceinline__ uint32_t desc_code(uint32_t w) { return __builtin_amdgcn_ubfe(w, 16, 8); }
-constexpr uint32_t DESC_LATE = 1u << 31;
-
 // cooking_env.py:352-373 get_feature_vector for every agent of the env: out[a][f] = lut[img[desc.hw] - sub[a][desc.code]]
 // P.wt selects the cache policy of the observation stores (wave-uniform; policy in cz_api.hip launch_step):
 //   1 = write-through (`buffer_store_dwordx4 ... sc1`): the bytes leave the XCD's L2 while the kernel still computes instead
@@ -351,7 +345,7 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
-            for (int j = 0; j < OBS_CHUNK; ++j) sb[a][j] = *reinterpret_cast<const int32_t *>(subb + 64 * a + desc_code(dsc[j]));
+            for (int j = 0; j < OBS_CHUNK; ++j) sb[a][j] = *reinterpret_cast<const int32_t *>(subb + 64 * a + (dsc[j] >> 16));
         double2_t v[NA][OBS_PAIRS];
 #pragma unroll
         for (int a = 0; a < NA; ++a)
@@ -384,14 +378,9 @@ struct StepOut {
 };
 
 // One accumulated_step (cooking_env.py:243-269) of one env held in registers.
-// `agents_final` is called once, at the point from which the agents' positions and orientations no longer change in this pass
-// (after the walking half of perform_agent_actions; after handle_agent_spawn when despawn / respawn is on; after a reset):
-// the two-waves-per-env kernel (cz_duo.h) publishes the agent words to its helper wave there; everybody else passes nothing.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <int OPL, int CPL, int NA, int SCHEME, class Hook = NoHook>
+template <int OPL, int CPL, int NA, int SCHEME>
 __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t acts,
-                                         int64_t env_global, uint32_t &rowv, Lds<CPL> &lds, uint32_t (&dsc)[OBS_CHUNK], Dirty &dt, StepOut &o,
-                                         Hook agents_final = Hook{}) {
+                                         int64_t env_global, uint32_t &rowv, Lds<CPL> &lds, uint32_t (&dsc)[OBS_CHUNK], Dirty &dt, StepOut &o) {
     using O = Ops<OPL, CPL, NA, SCHEME>;
     o.myrew = 0.0;
     o.term = 0; o.trunc = 0; o.stepped = false; o.finished = false; o.header = false; o.gone = 0u;
@@ -422,7 +411,6 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
             o.term = (e.status & ST_TERM) ? 1u : 0u;
             o.trunc = (e.status & ST_TRUNC) ? 1u : 0u;
         }
-        agents_final();
         return;
     }
     o.stepped = true;
@@ -432,17 +420,12 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
 #if defined(CZ_PROFILE)
     const int lane = cx.lane; const long long env = env_global - P.env_id_base;
 #endif
-    {                                                               // cooking_world.py:104-108 perform_agent_actions
-        const typename O::Pre pre = O::agents_walk(e, cx, acts, dt);
-        if (!spawning) agents_final();
-        O::agents_interact(e, cx, pre, dt);
-    }
+    O::perform_agent_actions(e, cx, acts, dt);                      // cooking_world.py:104-108
     CZ_STAMP(2);
     O::progress_and_link(e, cx, dt);
     if (spawning) {                             // :109-110 handle_agent_spawn
         o.gone = O::handle_agent_spawn(e, cx, spawn_cfg, env_global);
         o.header = true;                        // (the grace counters live in the status word)
-        agents_final();
     }
     CZ_STAMP(3);
     // compute_rewards cooking_env.py:290-315
@@ -870,10 +853,6 @@ __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) CZ_CHAIN_ATTR void k_step_
     step_kernel<OPL, CPL, NA, SCHEME, 0, true>(e_state, e_actions, e_lut, e_N, e_RW, e_W, e_H, e_D, e_dyn0, e_dyn1, e_seq, P0);
 }
 
-}  // namespace cz
-#include "cz_duo.h"
-namespace cz {
-
 // reset(): cooking_env.py:178-210 for envs [env_begin, env_begin + count)
 template <int OPL, int CPL, int NA>
 __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin, const int32_t *__restrict__ layout_ids,
@@ -925,10 +904,9 @@ __global__ __launch_bounds__(64) void k_observe(const Params P, int64_t env_begi
 }
 
 // launchers exported by each instantiation unit
-enum : int { LAUNCH_ONE = 0, LAUNCH_FUSED = 1, LAUNCH_DUO = 2 };
+enum : int { LAUNCH_ONE = 0, LAUNCH_FUSED = 1 };
 struct Launchers {
-    // mode: LAUNCH_ONE = one step; LAUNCH_FUSED = P.T steps per launch (actions: P.actions, or the on-device stream when null);
-    // LAUNCH_DUO = one step with two wavefronts per env (cz_duo.h; instances without it launch the ordinary kernel)
+    // mode: LAUNCH_ONE = one step; LAUNCH_FUSED = P.T steps per launch (actions: P.actions, or the on-device stream when null)
     hipError_t (*step)(const Params &, hipStream_t, int mode);
     hipError_t (*reset)(const Params &, hipStream_t, int64_t, int, const int32_t *, const uint32_t *, const uint32_t *, double *);
     hipError_t (*observe)(const Params &, hipStream_t, int64_t, int, double *);
@@ -976,12 +954,6 @@ struct Inst {
             else CZ_LAUNCH_STEP(1, 1);
         } else if (!P.actions) {
             return hipErrorInvalidValue;
-        } else if (mode == LAUNCH_DUO && OPL == 1 && CPL == 1 && !(P.seq & SEQ_PUBLISH)) {
-            if constexpr (OPL == 1 && CPL == 1) {
-                const dim3 dgrid((unsigned)((P.N + DUO_EPW - 1) / DUO_EPW)), dblock(64 * 2 * DUO_EPW);
-                if (P.scheme == 3) hipLaunchKernelGGL((k_step_duo<NA, 3>), dgrid, dblock, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, P);
-                else hipLaunchKernelGGL((k_step_duo<NA, 1>), dgrid, dblock, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, P);
-            }
         } else if (P.seq & SEQ_PUBLISH) {
             if constexpr (chain_instance<OPL, CPL, NA>()) {
                 if (P.scheme == 3) CZ_LAUNCH_CHAIN(3);
