@@ -52,7 +52,8 @@ SYMBOLS = [
     ("cz_update_layouts", C.c_int, [_VP, _I32, _I32, _VP, _VP]),
     ("cz_set_layout_group", C.c_int, [_VP, _I32, _I32]),
     ("cz_layout_updates", _I64, [_VP]),
-    ("cz_set_spawn", C.c_int, [_VP, C.c_double, C.c_double, _I32, _U64, _VP, _VP, _VP, _VP]),
+    ("cz_set_spawn", C.c_int, [_VP, C.c_double, C.c_double, _I32, _U64, _I32, _VP, _I32, _VP, _VP, _VP, _VP]),
+    ("cz_spawn_exhausted", _I64, [_VP]),
     ("cz_spawn_uniform", C.c_double, [_U64, _I64, _U32, _U32, _I32, _U32]),
     ("cz_set_state", C.c_int, [_VP, _I64, _I64, _VP]),
     ("cz_get_state", C.c_int, [_VP, _I64, _I64, _VP]),

@@ -171,6 +171,8 @@ struct cz_handle_s {
     hipEvent_t ev_main_copy_done = nullptr;
     int32_t lay_groups = 1, lay_active = 0;
     int64_t n_layout_updates = 0;
+    void *d_spawn_tables = nullptr;        // cz_set_spawn: exhausted-respawn counter | spawn areas per (level, agent) | level of every layout
+    int spawn_layouts = 0;                 // the pool size those tables were made for
     uint32_t *d_stat_u = nullptr;
     double *d_stat_f = nullptr;
     cz_stats *d_stats_out = nullptr;
@@ -265,7 +267,7 @@ static int chain_recover(cz_handle h) {
     *(volatile uint32_t *)h->h_chain_err = 0;
     return 0;
 }
-extern "C" int32_t cz_abi_version(void) { return 4; }
+extern "C" int32_t cz_abi_version(void) { return 5; }
 // diagnostic builds only (tools/phase_profile.py): where the kernels write their s_memtime stamps
 extern "C" int cz_debug_set_stamps(cz_handle h, void *d_buf) {
     if (!h) return 1;
@@ -481,7 +483,7 @@ extern "C" int cz_destroy(cz_handle h) {
         destroy_t f = (destroy_t)dlsym(h->rccl, "ncclCommDestroy");
         if (f) f(h->comm);
     }
-    void *ptrs[] = {h->d_reset_words, h->d_dump, h->d_lut, h->d_state, h->d_lay_block, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out, h->d_stats_part,
+    void *ptrs[] = {h->d_spawn_tables, h->d_reset_words, h->d_dump, h->d_lut, h->d_state, h->d_lay_block, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out, h->d_stats_part,
                     h->d_actions, h->d_obs, h->d_small, h->d_gather};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -517,11 +519,13 @@ extern "C" int cz_set_stream(cz_handle h, void *hip_stream) {
     h->tables_version++;
     return 0;
 }
-// Agent despawn / respawn for every world of the batch, on the device (cooking_world.py:267-290): from the next reset on.
-// rates 0 / 0 switch it off.  spawn_x / spawn_y: per agent the candidate coordinates of its spawn area (the level file's
-// AGENTS entries, parsing.py:118-151), 32 bytes each, n_x / n_y of them used.
+// Agent despawn / respawn for every world of the batch, on the device (cooking_world.py:267-290).  rates 0 / 0 switch it off.
+// The spawn areas come from the level files (their AGENTS entries, parsing.py:118-151), so they are per LEVEL: level_of_layout
+// says which level every layout of the resident pool instantiates (NULL: all of them level 0), spawn_x / spawn_y hold per
+// (level, agent) `stride` candidate coordinates of which the first n_x / n_y count.
 extern "C" int cz_set_spawn(cz_handle h, double despawn_rate, double respawn_rate, int32_t grace_period, uint64_t seed,
-                            const uint8_t *spawn_x, const int32_t *n_x, const uint8_t *spawn_y, const int32_t *n_y) {
+                            int32_t n_levels, const uint8_t *level_of_layout, int32_t stride, const uint8_t *spawn_x, const int32_t *n_x,
+                            const uint8_t *spawn_y, const int32_t *n_y) {
     if (!h) return fail(nullptr, "null handle");
     const bool on = despawn_rate > 0.0 || respawn_rate > 0.0;
     if (despawn_rate < 0.0 || respawn_rate < 0.0 || grace_period < 0 || grace_period > SPAWN_MAX_GRACE)
@@ -529,20 +533,62 @@ extern "C" int cz_set_spawn(cz_handle h, double despawn_rate, double respawn_rat
     SpawnCfg cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.seed = seed; cfg.despawn_rate = despawn_rate; cfg.respawn_rate = respawn_rate; cfg.grace_period = (uint32_t)grace_period;
+    std::vector<uint8_t> areas, levels;
     if (on) {
-        if (!spawn_x || !n_x || !spawn_y || !n_y) return fail(h, "cz_set_spawn: spawn areas missing");
-        for (int a = 0; a < h->P.A; ++a) {
-            if (n_x[a] < 1 || n_x[a] > 32 || n_y[a] < 1 || n_y[a] > 32) return fail(h, "cz_set_spawn: agent %d: 1..32 x and y candidates", a);
-            cfg.area[a].nx = (uint8_t)n_x[a]; cfg.area[a].ny = (uint8_t)n_y[a];
-            memcpy(cfg.area[a].xs, spawn_x + 32 * a, 32); memcpy(cfg.area[a].ys, spawn_y + 32 * a, 32);
+        if (!h->P.lay_init) return fail(h, "cz_set_spawn: load the layout pool first (the spawn areas are looked up by layout)");
+        if (!spawn_x || !n_x || !spawn_y || !n_y || n_levels < 1 || n_levels > 255 || stride < 1 || stride > 1024)
+            return fail(h, "cz_set_spawn: spawn areas missing, or not 1..255 levels with 1..1024 candidates per list");
+        const size_t blk = 4 + 2 * (size_t)stride;
+        areas.assign((size_t)n_levels * MAX_AGENTS * blk, 0);
+        for (int l = 0; l < n_levels; ++l)
+            for (int a = 0; a < h->P.A; ++a) {
+                const int nx = n_x[l * h->P.A + a], ny = n_y[l * h->P.A + a];
+                if (nx < 1 || nx > stride || ny < 1 || ny > stride)
+                    return fail(h, "cz_set_spawn: level %d, agent %d: 1..%d x and y candidates", l, a, stride);
+                uint8_t *b = areas.data() + ((size_t)l * MAX_AGENTS + a) * blk;
+                b[0] = (uint8_t)(nx & 255); b[1] = (uint8_t)(nx >> 8); b[2] = (uint8_t)(ny & 255); b[3] = (uint8_t)(ny >> 8);
+                memcpy(b + 4, spawn_x + ((size_t)l * h->P.A + a) * stride, (size_t)stride);
+                memcpy(b + 4 + stride, spawn_y + ((size_t)l * h->P.A + a) * stride, (size_t)stride);
+            }
+        levels.assign((size_t)h->n_layouts, 0);
+        for (int i = 0; i < h->n_layouts; ++i) {
+            const int lv = level_of_layout ? level_of_layout[i] : 0;
+            if (lv >= n_levels) return fail(h, "cz_set_spawn: layout %d is of level %d, but only %d level(s) have spawn areas", i, lv, n_levels);
+            levels[(size_t)i] = (uint8_t)lv;
         }
     }
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->aux_stream) HIPCHK(h, hipStreamSynchronize(h->aux_stream));
+    if (h->d_spawn_tables) { HIPCHK(h, hipFree(h->d_spawn_tables)); h->d_spawn_tables = nullptr; }
+    h->spawn_layouts = 0;
+    if (on) {
+        // one allocation: the counter word, the areas, the level of every layout
+        const size_t off_areas = 16, off_levels = off_areas + ((areas.size() + 15) & ~(size_t)15);
+        HIPCHK(h, hipMalloc(&h->d_spawn_tables, off_levels + levels.size() + 16));
+        HIPCHK(h, hipMemset(h->d_spawn_tables, 0, off_levels + levels.size() + 16));
+        HIPCHK(h, hipMemcpy((char *)h->d_spawn_tables + off_areas, areas.data(), areas.size(), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy((char *)h->d_spawn_tables + off_levels, levels.data(), levels.size(), hipMemcpyHostToDevice));
+        cfg.stride = (uint32_t)stride;
+        cfg.exhausted = (uint32_t *)h->d_spawn_tables;
+        cfg.areas = (const uint8_t *)h->d_spawn_tables + off_areas;
+        cfg.level_of_layout = (const uint8_t *)h->d_spawn_tables + off_levels;
+        h->spawn_layouts = h->n_layouts;
+    }
     HIPCHK(h, hipMemcpy((char *)h->d_lut + SPAWN_CFG_OFFSET, &cfg, sizeof cfg, hipMemcpyHostToDevice));
     h->P.auto_reset = (h->P.auto_reset & 1) | (on ? 2 : 0);
     h->tables_version++;
     return 0;
+}
+// respawns that found no free cell of their spawn area within generate_location's 1001 tries (parsing.py:154-167 raises
+// ValueError there; the device leaves the agent where it stood) since cz_set_spawn; -1 on error
+extern "C" int64_t cz_spawn_exhausted(cz_handle h) {
+    if (!h) return -1;
+    if (!h->d_spawn_tables) return 0;
+    uint32_t n = 0;
+    if (hipSetDevice(h->cfg.device_id) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess ||
+        hipMemcpy(&n, h->d_spawn_tables, 4, hipMemcpyDeviceToHost) != hipSuccess) { fail(h, "cz_spawn_exhausted: copy failed"); return -1; }
+    return (int64_t)n;
 }
 // the draw the device takes (host mirror, for parity tests): uniform in [0, 1), keyed by (seed, global env id, episode << 32 | t,
 // agent, draw index)
@@ -874,6 +920,9 @@ static int ready(cz_handle h) {
 
 static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr, bool fused = false) {
     if (chain_failed(h, "step launch")) return 1;
+    if ((P.auto_reset & 2) && h->spawn_layouts != h->n_layouts)
+        return fail(h, "despawn / respawn is on, but the layout pool was reloaded with another size (%d -> %d layouts): call cz_set_spawn "
+                       "again (it maps every layout to the level whose spawn areas it uses)", h->spawn_layouts, h->n_layouts);
     if (!stream) stream = h->stream;
     // write-through observation stores pay when the launch is short enough for the end-of-kernel L2 write-back to be
     // exposed: one step of a moderate batch; streaming stores when one launch's observations do not fit the memory-side

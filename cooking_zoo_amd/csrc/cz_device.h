@@ -157,14 +157,19 @@ enum : uint32_t { LC_GROUPS = 0, LC_ACTIVE = 1 };
 struct SpawnCfg {
     uint64_t seed;
     double despawn_rate, respawn_rate;
-    uint32_t grace_period, pad;
-    struct Area { uint8_t nx, ny, pad[2]; uint8_t xs[32], ys[32]; } area[MAX_AGENTS];      // the level file's spawn areas (parsing.py:118-151)
+    uint32_t grace_period;
+    uint32_t stride;                   // bytes per candidate list
+    // the level files' spawn areas (parsing.py:118-151), one block per (level, agent): n_x, n_y (two uint16), then `stride` x
+    // candidates and `stride` y candidates (bytes); which level a world belongs to follows from its layout
+    const uint8_t *areas;              // [n_levels][MAX_AGENTS][4 + 2 * stride]
+    const uint8_t *level_of_layout;    // [L]
+    uint32_t *exhausted;               // counts respawns that found no free cell in 1001 tries (the reference raises there)
 };
-static_assert(sizeof(SpawnCfg) == 32 + 4 * 68, "layout of the block behind Params::lut");
+static_assert(sizeof(SpawnCfg) == 56, "layout of the block behind Params::lut");
 constexpr uint32_t SPAWN_CFG_OFFSET = 256 * 8 + 64 * 4;      // bytes behind Params::lut: the 256 doubles and the 64 submask words
 // ... then two more per-lane constant tables (cz_create): the cell-coordinate image words of cells 0..1023, and for lane l
 // which word of which recipe row it holds (load_recipe_rows): 8 r | 4 i << 8 for word i of the env's r-th recipe
-constexpr uint32_t COORD_TABLE_OFFSET = SPAWN_CFG_OFFSET + 32 + 4 * 68, ROWSEL_TABLE_OFFSET = COORD_TABLE_OFFSET + 1024 * 4;
+constexpr uint32_t COORD_TABLE_OFFSET = SPAWN_CFG_OFFSET + 56, ROWSEL_TABLE_OFFSET = COORD_TABLE_OFFSET + 1024 * 4;
 constexpr uint32_t LUT_BLOCK_BYTES = ROWSEL_TABLE_OFFSET + 64 * 4;
 // status word: bit 8 + a = agent a is despawned; bits 12 + 5 a .. 16 + 5 a = its grace countdown
 constexpr int SPAWN_GONE0 = 8, SPAWN_GRACE0 = 12, SPAWN_GRACE_BITS = 5, SPAWN_MAX_GRACE = 31;
@@ -734,21 +739,29 @@ struct Ops {
                 }
             } else if (spawn_uniform(seed, (uint64_t)env_global, key, (uint32_t)a, 1u) < respawn_rate) {
                 // respawn_agent: back, grace period restarted, on a Floor cell of its spawn area that nobody - active or
-                // not, itself included - stands on (generate_location: up to 1001 tries)
+                // not, itself included - stands on (generate_location: up to 1001 tries; the reference raises ValueError when
+                // they are used up or a candidate lies beyond the grid, here such candidates are skipped, the agent comes
+                // back where it stood and the handle counts the event: cz_spawn_exhausted)
                 st = (st & ~(1u << (SPAWN_GONE0 + a))) | (cfg->grace_period << gsh);
-                const uint32_t nx = cfg->area[a].nx, ny = cfg->area[a].ny;
+                typedef const __attribute__((address_space(4))) uint8_t *kbytes;
+                const uint32_t stride = cfg->stride, level = ((kbytes)cfg->level_of_layout)[e.layout];
+                const kbytes blk = (kbytes)cfg->areas + (size_t)(level * (uint32_t)MAX_AGENTS + (uint32_t)a) * (4u + 2u * stride);
+                const uint32_t nx = (uint32_t)blk[0] | ((uint32_t)blk[1] << 8), ny = (uint32_t)blk[2] | ((uint32_t)blk[3] << 8);
+                bool placed = false;
 #pragma nounroll
                 for (uint32_t k = 0; k < 1001u; ++k) {
                     const uint32_t ix = (uint32_t)(spawn_uniform(seed, (uint64_t)env_global, key, (uint32_t)a, 2u + 2u * k) * (double)nx);
                     const uint32_t iy = (uint32_t)(spawn_uniform(seed, (uint64_t)env_global, key, (uint32_t)a, 3u + 2u * k) * (double)ny);
-                    const uint32_t x = cfg->area[a].xs[ix], y = cfg->area[a].ys[iy];
+                    const uint32_t x = blk[4u + ix], y = blk[4u + stride + iy];
                     if (x >= (uint32_t)cx.W || y >= (uint32_t)cx.H) continue;
                     if ((cell_at(e, (int)(y * (uint32_t)cx.W + x)) & CELL_TYPE) != FLOOR) continue;
                     const uint32_t xy = x | (y << 8);
                     if (ballot((e.agw & 0xFFFFu) == xy) & ((1ull << NA) - 1ull)) continue;
                     e.agw = wrl((rdl(e.agw, a) & 0xFFFF0000u) | xy, a, e.agw);         // the location only (cooking_world.py:290)
+                    placed = true;
                     break;
                 }
+                if (!placed && cx.lane == 0) atomicAdd(cfg->exhausted, 1u);
             }
         }
         e.status = st;

@@ -42,11 +42,14 @@ def uniform(seed, env_global, step, agent, draw):
 
 
 class SpawnBook:
-    def __init__(self, num_envs, num_agents, spawn_cells, *, despawn_rate, respawn_rate, grace_period, seed=0, env_id_base=0):
-        """spawn_cells[i] = (x candidates, y candidates) of agent i (the level file's AGENTS entries, parsing.py:118-151)"""
+    def __init__(self, num_envs, num_agents, spawn_cells, *, despawn_rate, respawn_rate, grace_period, seed=0, env_id_base=0,
+                 level_of_layout=None):
+        """spawn_cells[level][i] = (x candidates, y candidates) of agent i in that level (the level file's AGENTS entries,
+        parsing.py:118-151); level_of_layout[layout id] = the level a layout instantiates (None: one level)"""
         self.N, self.A = int(num_envs), int(num_agents)
         self.despawn_rate, self.respawn_rate, self.grace_period = float(despawn_rate), float(respawn_rate), int(grace_period)
-        self.spawn_cells = [(list(xs), list(ys)) for xs, ys in spawn_cells]
+        self.spawn_cells = [[(list(xs), list(ys)) for xs, ys in lv] for lv in spawn_cells]
+        self.level_of_layout = None if level_of_layout is None else np.asarray(level_of_layout, dtype=np.int64)
         self.seed, self.env_id_base = int(seed), int(env_id_base)
         self.env_ids = np.arange(self.N, dtype=np.uint64) + np.uint64(self.env_id_base)
         self.reset_all()
@@ -107,7 +110,8 @@ class SpawnBook:
 
     def _generate_location(self, rec, dims, agent, e):
         """parsing.py:154-167: a Floor cell nobody (active or not) stands on, from the agent's spawn area"""
-        xs, ys = self.spawn_cells[agent]
+        level = 0 if self.level_of_layout is None else int(self.level_of_layout[int(rec[soa.W_LAYOUT])])
+        xs, ys = self.spawn_cells[level][agent]
         cells = soa.record_cells(dims, rec)
         taken = {soa.unpack_agent(rec[soa.AGENT_WORD0 + a])[:2] for a in range(dims.A)}
         for k in range(1001):

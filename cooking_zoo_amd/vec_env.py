@@ -223,21 +223,40 @@ class CookingVecEnv:
         self._rot = None                      # rotate_layouts state
         self.rotation_events = []             # (step index, "group", groups, active) / (step index, "layouts", first slot, [Layout])
         if self._spawn_cfg[0] or self._spawn_cfg[1]:
-            if len(self.levels) != 1:
-                raise ValueError("agent despawn / respawn needs one level per batch (the spawn areas come from the level file)")
-            cells = [(spec["X_POSITION"], spec["Y_POSITION"]) for spec in self.level_objects[0]["AGENTS"]
-                     for _ in range(spec["MAX_COUNT"])][:self.num_agents]                       # parsing.py:145
-            self.spawn_cells = [(list(xs), list(ys)) for xs, ys in cells]
-            sx, sy = np.zeros((self.num_agents, 32), dtype=np.uint8), np.zeros((self.num_agents, 32), dtype=np.uint8)
-            nx, ny = np.zeros(self.num_agents, dtype=np.int32), np.zeros(self.num_agents, dtype=np.int32)
-            for a, (xs, ys) in enumerate(self.spawn_cells):
-                if not (1 <= len(xs) <= 32 and 1 <= len(ys) <= 32):
-                    raise ValueError("a spawn area lists 1..32 x and y candidates")
-                nx[a], ny[a] = len(xs), len(ys)
-                sx[a, :len(xs)], sy[a, :len(ys)] = xs, ys
-            _native.check(self._h, L.cz_set_spawn(self._h, self._spawn_cfg[0], self._spawn_cfg[1], self._spawn_cfg[2], self._spawn_cfg[3],
-                                                  _ptr(sx), _ptr(nx), _ptr(sy), _ptr(ny)))
+            # spawn areas per level (parsing.py:118-151: the AGENTS entries of the level file, one per agent up to MAX_COUNT each)
+            self.spawn_cells = []                                        # [level][agent] -> (x candidates, y candidates)
+            for lv in self.level_objects:
+                cells = [(spec["X_POSITION"], spec["Y_POSITION"]) for spec in lv["AGENTS"] for _ in range(spec["MAX_COUNT"])][:self.num_agents]   # parsing.py:145
+                self.spawn_cells.append([(list(xs), list(ys)) for xs, ys in cells])
+            self.level_of_layout = np.zeros(len(self.layouts), dtype=np.uint8)
+            for li, (base, count) in enumerate(self.pool_slices):
+                self.level_of_layout[base:base + count] = li
+            self._set_spawn()
             self.spawn = SpawnView(self)
+
+    def _set_spawn(self):
+        L, nl, A = _native.lib(), len(self.spawn_cells), self.num_agents
+        stride = max(max(len(xs), len(ys)) for lv in self.spawn_cells for xs, ys in lv)
+        if not 1 <= stride <= 1024:
+            raise ValueError("a spawn area lists 1..1024 x and y candidates")
+        sx, sy = np.zeros((nl, A, stride), dtype=np.uint8), np.zeros((nl, A, stride), dtype=np.uint8)
+        nx, ny = np.zeros((nl, A), dtype=np.int32), np.zeros((nl, A), dtype=np.int32)
+        for li, lv in enumerate(self.spawn_cells):
+            if len(lv) < A:
+                raise ValueError(f"level {self.levels[li]} has spawn areas for {len(lv)} agent(s) only")
+            for a, (xs, ys) in enumerate(lv):
+                if not xs or not ys:
+                    raise ValueError("a spawn area lists 1..1024 x and y candidates")
+                nx[li, a], ny[li, a] = len(xs), len(ys)
+                # (a candidate beyond the grid can never be taken: 255 stands for any of them)
+                sx[li, a, :len(xs)] = [v if 0 <= v < 255 else 255 for v in xs]
+                sy[li, a, :len(ys)] = [v if 0 <= v < 255 else 255 for v in ys]
+        d, r, g, seed = self._spawn_cfg
+        _native.check(self._h, L.cz_set_spawn(self._h, d, r, g, seed, nl, _ptr(self.level_of_layout), stride, _ptr(sx), _ptr(nx), _ptr(sy), _ptr(ny)))
+
+    def spawn_exhausted(self):
+        """respawns that found no free cell of their spawn area in 1001 tries (the reference raises there) since the env was made"""
+        return int(_native.lib().cz_spawn_exhausted(self._h))
 
     # ------------------------------------------------------------------ tables
     def _upload_layouts(self):
@@ -251,6 +270,9 @@ class CookingVecEnv:
         self.layouts = list(layouts)
         self.pool_slices = [(0, len(self.layouts))]
         self._upload_layouts()
+        if self.spawn is not None:                                       # (the spawn tables map every layout of the pool to its level)
+            self.level_of_layout = np.zeros(len(self.layouts), dtype=np.uint8)
+            self._set_spawn()
 
     # ------------------------------------------------------------------ fresh layouts under a stepping batch
     def update_layouts(self, first, layouts):

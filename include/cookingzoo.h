@@ -119,16 +119,26 @@ int64_t cz_layout_updates(cz_handle h);
 
 /* Agent despawn / respawn (cooking_world.py:267-290 handle_agent_spawn, despawn_agent, respawn_agent; parsing.py:154-167
  * generate_location) for every world of the batch, evaluated by the step kernels themselves - on every path: cz_step,
- * cz_step_device*, overlapped runs, cz_rollout.  The reference takes its draws from numpy's process-global stream, which
- * defines them for one world per process; here every draw comes from a counter-based stream keyed by (seed, global env id,
- * episode << 32 | t, agent, draw index) (cz_spawn_uniform is the host mirror), so results depend neither on the batch size
- * nor on the sharding nor on the launch form.  The record's status word carries a "despawned" bit per agent (bit 8 + agent)
- * and a 5-bit grace countdown each (from bit 12 + 5 * agent).  A despawned agent does not act (as with action -1), is reported truncated in the
- * step it leaves, and stays in the world as an obstacle; an agent that holds something stays.  Takes effect with the next
- * cz_reset / auto-reset (fresh worlds start with everybody present and the grace period running); rates 0, 0 switch it
- * off.  spawn_x / spawn_y: [num_agents][32] candidate coordinates (the level file's AGENTS entries), n_x / n_y how many. */
+ * cz_step_device*, overlapped runs, cz_rollout, cz_rollout_actions.  The reference takes its draws from numpy's process-global
+ * stream, which defines them for one world per process; here every draw comes from a counter-based stream keyed by (seed,
+ * global env id, episode << 32 | t, agent, draw index) (cz_spawn_uniform is the host mirror), so results depend neither on the
+ * batch size nor on the sharding nor on the launch form; tests/golden/spawn_keyed_*.npz are trajectories of the unmodified
+ * reference functions fed with exactly these draws.  The record's status word carries a "despawned" bit per agent (bit 8 +
+ * agent) and a 5-bit grace countdown each (from bit 12 + 5 * agent).  A despawned agent does not act (whatever its action
+ * says), is reported truncated in the step it leaves, and stays in the world as an obstacle; an agent that holds something stays.
+ * TAKES EFFECT WITH THE NEXT STEP: worlds reset from then on start with everybody present and the grace period running
+ * (parsing.py:142); episodes that are already running continue with whatever their status words hold (grace 0 unless the
+ * caller set it), i.e. they draw from their next step on.  Rates 0, 0 switch it off.
+ * Spawn areas (the level files' AGENTS entries, parsing.py:118-151) are per level: level_of_layout[i] (NULL: all 0) is the
+ * level that layout i of the resident pool instantiates - call again after cz_load_layouts changed the pool size -,
+ * spawn_x / spawn_y are [n_levels][num_agents][stride] candidate coordinates, n_x / n_y [n_levels][num_agents] how many of
+ * them count (1..stride, stride <= 1024).  Differences from the reference, which raises in both cases: a candidate outside the
+ * grid is skipped, and a respawn that finds no free Floor cell in 1001 tries puts the agent back where it stood -
+ * cz_spawn_exhausted counts those. */
 int cz_set_spawn(cz_handle h, double despawn_rate, double respawn_rate, int32_t grace_period, uint64_t seed,
-                 const uint8_t *spawn_x, const int32_t *n_x, const uint8_t *spawn_y, const int32_t *n_y);
+                 int32_t n_levels, const uint8_t *level_of_layout, int32_t stride, const uint8_t *spawn_x, const int32_t *n_x,
+                 const uint8_t *spawn_y, const int32_t *n_y);
+int64_t cz_spawn_exhausted(cz_handle h);
 double cz_spawn_uniform(uint64_t seed, int64_t env_global, uint32_t episode, uint32_t t, int32_t agent, uint32_t draw);
 
 /* ---- state ----------------------------------------------------------------------------------------- */

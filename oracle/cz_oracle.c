@@ -6,7 +6,7 @@
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  * The product path (cooking_zoo_amd + libcookingzoo_hip.so) never links, imports or calls it.
  *
- * Parity status: PINNED.  tests/test_oracle_golden.py replays every golden trace under
+ * Parity status: PINNED.  tests/test_oracle_golden.py (and test_spawn_keyed.py) replay every golden trace under
  * tests/golden/ (captured by tools/gen_golden.py from the unmodified reference imported in the
  * build container, incl. SURVEY.md Appendix C.3's known-answer trace) and requires bit-equality
  * of state, float64 observations, float64 rewards and flags at every step.
@@ -568,7 +568,8 @@ static void resolve_linked_interactions(World *w)
     }
 }
 
-/* cooking_world.py:104-112 world_step (handle_agent_spawn is behaviour-neutral at the default 0.0 rates) */
+/* cooking_world.py:104-112 world_step (its last call, handle_agent_spawn, is made by czo_step_env: it needs the record's
+   status word and the keys of the draws) */
 static void world_step(World *w, const int *actions)
 {
     perform_agent_actions(w, actions);
@@ -743,7 +744,96 @@ typedef struct {
     int64_t env_id_base;              /* global id of env 0 (shard offset) */
     int32_t pool_groups, pool_active; /* auto-reset draws come from part pool_active of every pool slice cut into pool_groups
                                          equal parts (0 or 1 groups: the whole slice) -- mirrors cz_set_layout_group */
+    const struct czo_spawn *spawn;    /* agent despawn / respawn with keyed draws (NULL: off) -- mirrors cz_set_spawn */
 } czo_ctx;
+
+/* Agent despawn / respawn for a batch of worlds: the reference's rule (cooking_world.py:267-290) with every draw taken from
+ * a counter-based stream instead of numpy's / Python's process-global ones.  Pinned by tests/golden/spawn_keyed_*.npz:
+ * trajectories of the UNMODIFIED reference functions whose np.random.random / random.sample were fed with exactly these draws
+ * (tools/gen_golden.py capture_spawn_keyed_episode). */
+typedef struct czo_spawn {
+    double despawn_rate, respawn_rate;
+    uint64_t seed;
+    int32_t grace_period;
+    int32_t n_levels, stride;         /* spawn areas per level: up to `stride` candidates per list */
+    const uint8_t *level_of_layout;   /* [num_layouts]; NULL: every layout is level 0 */
+    const int32_t *n_x, *n_y;         /* [n_levels][num_agents] */
+    const int32_t *xs, *ys;           /* [n_levels][num_agents][stride]: X_POSITION / Y_POSITION of the level file's AGENTS entries */
+} czo_spawn;
+
+/* status word: bit 8 + a = agent a is despawned (not in world.active_agents), bits 12 + 5 a .. = world.agent_grace_period[a] */
+enum { SPAWN_GONE0 = 8, SPAWN_GRACE0 = 12, SPAWN_GRACE_BITS = 5 };
+
+/* the keyed stream: splitmix64 finaliser over (seed, global env id), (episode << 32 | t), (agent, draw index) -> [0, 1) */
+static uint64_t spawn_mix(uint64_t x)
+{
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+double czo_spawn_uniform(uint64_t seed, uint64_t env_global, uint64_t step_key, uint32_t agent, uint32_t draw)
+{
+    uint64_t k = spawn_mix(seed + 0x9E3779B97F4A7C15ull * env_global);
+    k = spawn_mix(k ^ (step_key * 0xD1B54A32D192ED03ull));
+    k = spawn_mix(k ^ ((uint64_t)agent << 32) ^ (uint64_t)draw);
+    return (double)(k >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* parsing.py:154-167 generate_location: random.sample(x_positions, 1)[0], random.sample(y_positions, 1)[0] until the cell is a
+   Floor nobody (active or not) stands on; up to 1001 tries.  Draw 2 + 2 k picks x, draw 3 + 2 k picks y in try k.  Returns 0 if
+   no try succeeded (the reference raises ValueError; so it does for a candidate beyond the grid, which is skipped here). */
+static int generate_location(const World *w, const czo_spawn *sp, int level, int agent, uint64_t env_global, uint64_t key, int *ox, int *oy)
+{
+    const int A = w->A;
+    const int nx = sp->n_x[level * A + agent], ny = sp->n_y[level * A + agent];
+    const int32_t *xs = sp->xs + ((size_t)level * A + agent) * sp->stride, *ys = sp->ys + ((size_t)level * A + agent) * sp->stride;
+    for (int time_out = 0; time_out <= 1000; ++time_out) {
+        int x = xs[(int)(czo_spawn_uniform(sp->seed, env_global, key, (uint32_t)agent, 2u + 2u * (uint32_t)time_out) * (double)nx)];
+        int y = ys[(int)(czo_spawn_uniform(sp->seed, env_global, key, (uint32_t)agent, 3u + 2u * (uint32_t)time_out) * (double)ny)];
+        if (x < 0 || y < 0 || x >= w->W || y >= w->H) continue;
+        if (w->cell[y * w->W + x].type != FLOOR) continue;                  /* world.get_objects_at((x, y), Floor) */
+        int taken = 0;
+        for (int j = 0; j < A; ++j) if (w->ag[j].x == x && w->ag[j].y == y) taken = 1;     /* any agent, active or not */
+        if (taken) continue;
+        *ox = x; *oy = y;
+        return 1;
+    }
+    return 0;
+}
+
+/* cooking_world.py:267-277 handle_agent_spawn (+ despawn_agent :279-285, respawn_agent :286-290) on the unpacked world;
+   `status` = the record's status word (despawned bits, grace counters).  Returns the agents that left in this step (bit a):
+   cooking_env.py:344-349 reports them truncated once. */
+static uint32_t handle_agent_spawn(World *w, const czo_spawn *sp, uint32_t *status, int level, uint64_t env_global, uint64_t key)
+{
+    uint32_t st = *status, gone = 0;
+    for (int i = 0; i < w->A; ++i) {
+        const int gsh = SPAWN_GRACE0 + SPAWN_GRACE_BITS * i;
+        if ((st >> gsh) & 31u) { st -= 1u << gsh; continue; }             /* agent_grace_period[i] -= 1 */
+        int n_active = 0;
+        for (int j = 0; j < w->A; ++j) n_active += !((st >> (SPAWN_GONE0 + j)) & 1u);
+        const int active = !((st >> (SPAWN_GONE0 + i)) & 1u);
+        /* the `and` chain draws only when it gets that far; an `elif` arm is looked at only when the `if` test failed */
+        if (n_active > 1 && active && czo_spawn_uniform(sp->seed, env_global, key, (uint32_t)i, 0u) < sp->despawn_rate) {
+            if (w->ag[i].holding >= 0) continue;                           /* despawn_agent: an agent that holds something stays */
+            st |= 1u << (SPAWN_GONE0 + i);
+            gone |= 1u << i;
+        } else if (!active && czo_spawn_uniform(sp->seed, env_global, key, (uint32_t)i, 1u) < sp->respawn_rate) {
+            st &= ~(1u << (SPAWN_GONE0 + i));                              /* respawn_agent */
+            st |= (uint32_t)sp->grace_period << gsh;
+            int x, y;
+            if (generate_location(w, sp, level, i, env_global, key, &x, &y)) { w->ag[i].x = x; w->ag[i].y = y; }   /* the location only (:290) */
+        }
+    }
+    *status = st;
+    return gone;
+}
+static uint32_t spawn_initial_status(const czo_spawn *sp, int A)     /* load_level.py:67-68, parsing.py:142 */
+{
+    uint32_t st = 0;
+    for (int a = 0; a < A; ++a) st |= (uint32_t)sp->grace_period << (SPAWN_GRACE0 + SPAWN_GRACE_BITS * a);
+    return st;
+}
 
 static void recompute_marks(const czo_ctx *cx, World *w, uint32_t *rec)
 {
@@ -792,6 +882,7 @@ int czo_reset_env(const czo_ctx *cx, int64_t env_local, uint32_t layout_id, uint
     uint32_t recipes = rec[W_RECIPES], episode = rec[W_EPISODE], pool = rec[W_POOL];
     memcpy(rec, cx->layouts[layout_id].init_record, sizeof(uint32_t) * (size_t)cfg->record_words);
     rec[W_T] = 0; rec[W_LAYOUT] = layout_id; rec[W_STATUS] = 0; rec[W_EPISODE] = episode; rec[W_RECIPES] = recipes; rec[W_POOL] = pool;
+    if (cx->spawn) rec[W_STATUS] = spawn_initial_status(cx->spawn, cfg->num_agents);
     static __thread World w;
     unpack(&w, cfg, rec);
     recompute_marks(cx, &w, rec);
@@ -829,7 +920,17 @@ int czo_step_env(const czo_ctx *cx, int64_t env_local, uint32_t *rec, const int3
     rec[W_T] += 1;                                              /* cooking_env.py:244 */
     int acts[CZO_MAX_AGENTS];
     for (int a = 0; a < A; ++a) acts[a] = actions[a];
-    world_step(&w, acts);                                       /* :246 */
+    uint32_t gone = 0;
+    if (cx->spawn) {
+        /* a despawned agent is not in the list world_step acts on (cooking_world.py:105-108) */
+        for (int a = 0; a < A; ++a) if ((rec[W_STATUS] >> (SPAWN_GONE0 + a)) & 1u) acts[a] = -1;
+    }
+    world_step(&w, acts);                                       /* :246 (its last call, handle_agent_spawn, follows) */
+    if (cx->spawn) {
+        const int level = cx->spawn->level_of_layout ? cx->spawn->level_of_layout[rec[W_LAYOUT]] : 0;
+        gone = handle_agent_spawn(&w, cx->spawn, &rec[W_STATUS], level, (uint64_t)(cx->env_id_base + env_local),
+                                  ((uint64_t)rec[W_EPISODE] << 32) | (uint64_t)rec[W_T]);
+    }
 
     /* compute_rewards :290-315 */
     int truncated = (int)rec[W_T] >= cfg->max_steps;            /* compute_truncated :333-350 */
@@ -856,7 +957,7 @@ int czo_step_env(const czo_ctx *cx, int64_t env_local, uint32_t *rec, const int3
         n_completed += completed;
     }
     int done = cfg->end_condition_all ? (n_completed == cfg->num_recipes) : (n_completed > 0);
-    for (int a = 0; a < A; ++a) { rewards[a] = rew[a]; term[a] = (uint8_t)done; trunc[a] = (uint8_t)truncated; }
+    for (int a = 0; a < A; ++a) { rewards[a] = rew[a]; term[a] = (uint8_t)done; trunc[a] = (uint8_t)(truncated || ((gone >> a) & 1u)); }
     if (done || truncated)
         rec[W_STATUS] |= STATUS_DONE | (done ? STATUS_TERM : 0) | (truncated ? STATUS_TRUNC : 0);
     pack(&w, rec);

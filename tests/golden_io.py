@@ -27,7 +27,15 @@ def golden_sets():
 def spawn_sets():
     """Sets captured with agent despawn / respawn on: per-step fixtures (start state, actions with -1 for inactive agents,
     the world right before the spawn bookkeeping), not one chain -- see tools/gen_golden.py capture_spawn_episode."""
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "spawn_*.npz")))
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "spawn_*.npz"))
+                  if not os.path.basename(p).startswith("spawn_keyed_"))
+
+
+def spawn_keyed_sets():
+    """Sets captured from the reference with despawn / respawn on AND every draw of handle_agent_spawn / generate_location
+    answered by the batched build's keyed stream (tools/gen_golden.py capture_spawn_keyed_episode): whole trajectories a
+    batched env with the same (seed, env id, episode) key must reproduce, status word included."""
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "spawn_keyed_*.npz")))
 
 
 class Episode:
@@ -42,6 +50,8 @@ class Episode:
         self.class_order = meta_ep["class_order"]
         self.seed = meta_ep["seed"]
         self.policy = meta_ep["policy"]
+        self.env_id, self.episode_no = meta_ep.get("env_id"), meta_ep.get("episode_no")      # keyed despawn / respawn sets
+        self.spawn_areas = meta_ep.get("spawn_areas")                                        # [agent] -> [x candidates, y candidates]
 
     def static_table(self):
         W = self.dims.W

@@ -31,10 +31,16 @@ class CzoMeta(C.Structure):
     _fields_ = [("cls", C.c_int), ("num", C.c_int)]
 
 
+class CzoSpawn(C.Structure):
+    _fields_ = [("despawn_rate", C.c_double), ("respawn_rate", C.c_double), ("seed", C.c_uint64), ("grace_period", C.c_int32),
+                ("n_levels", C.c_int32), ("stride", C.c_int32), ("level_of_layout", C.c_void_p), ("n_x", C.c_void_p),
+                ("n_y", C.c_void_p), ("xs", C.c_void_p), ("ys", C.c_void_p)]
+
+
 class CzoCtx(C.Structure):
     _fields_ = [("cfg", C.POINTER(CzoConfig)), ("recipe_table", C.c_void_p), ("layouts", C.POINTER(CzoLayout)),
                 ("meta", C.POINTER(CzoMeta)), ("n_meta", C.c_int), ("env_id_base", C.c_int64),
-                ("pool_groups", C.c_int32), ("pool_active", C.c_int32)]
+                ("pool_groups", C.c_int32), ("pool_active", C.c_int32), ("spawn", C.POINTER(CzoSpawn))]
 
 
 def load_lib():
@@ -47,6 +53,8 @@ def load_lib():
     lib.czo_action.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_uint32, C.c_uint32]
     lib.czo_next_layout.restype = C.c_uint32
     lib.czo_next_layout.argtypes = [C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.czo_spawn_uniform.restype = C.c_double
+    lib.czo_spawn_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
     return lib
 
 
@@ -84,7 +92,27 @@ class Oracle:
             self.layout_arr[i] = CzoLayout(rec.ctypes.data, off.ctypes.data, cells.ctypes.data)
         self.meta_arr = (CzoMeta * len(meta))(*[CzoMeta(meta_class_id(k), int(v)) for k, v in meta.items()])
         self.ctx = CzoCtx(C.pointer(self.cfg), self.recipe_table.ctypes.data, self.layout_arr, self.meta_arr,
-                          len(meta), int(env_id_base), 1, 0)
+                          len(meta), int(env_id_base), 1, 0, None)
+
+    def set_spawn(self, despawn_rate, respawn_rate, grace_period, seed, spawn_cells, level_of_layout=None):
+        """agent despawn / respawn with keyed draws (mirror of cz_set_spawn): spawn_cells[level][agent] = (x candidates, y
+        candidates) as the level file lists them; level_of_layout[layout id] = level (None: one level).  Rates 0, 0: off."""
+        if not (despawn_rate or respawn_rate):
+            self.ctx.spawn = None
+            return
+        A, nl = self.dims.A, len(spawn_cells)
+        stride = max(max(len(xs), len(ys)) for lv in spawn_cells for xs, ys in lv)
+        xs_a, ys_a = np.zeros((nl, A, stride), dtype=np.int32), np.zeros((nl, A, stride), dtype=np.int32)
+        nx, ny = np.zeros((nl, A), dtype=np.int32), np.zeros((nl, A), dtype=np.int32)
+        for li, lv in enumerate(spawn_cells):
+            for a, (xs, ys) in enumerate(lv[:A]):
+                nx[li, a], ny[li, a] = len(xs), len(ys)
+                xs_a[li, a, :len(xs)], ys_a[li, a, :len(ys)] = xs, ys
+        lol = None if level_of_layout is None else np.ascontiguousarray(level_of_layout, dtype=np.uint8)
+        self._spawn_keep = (xs_a, ys_a, nx, ny, lol)
+        self._spawn = CzoSpawn(float(despawn_rate), float(respawn_rate), int(seed), int(grace_period), nl, stride,
+                               None if lol is None else lol.ctypes.data, nx.ctypes.data, ny.ctypes.data, xs_a.ctypes.data, ys_a.ctypes.data)
+        self.ctx.spawn = C.pointer(self._spawn)
 
     def set_layout(self, i, rec, off, cells):
         """replace layout i of the pool (mirror of cz_update_layouts)"""
@@ -171,6 +199,14 @@ class VecOracle:
     @classmethod
     def from_vec_env(cls, env, num_envs=None, env_id_base=None, auto_reset=1):
         n = env.num_envs if num_envs is None else num_envs
+        me = cls._from_vec_env(env, n, env_id_base, auto_reset)
+        if getattr(env, "spawn", None) is not None:              # the batch evaluates despawn / respawn on the device: so does its twin
+            d, r, g, seed = env._spawn_cfg
+            me.oracle.set_spawn(d, r, g, seed, env.spawn_cells, env.level_of_layout)
+        return me
+
+    @classmethod
+    def _from_vec_env(cls, env, n, env_id_base, auto_reset):
         return cls(layouts=env.layouts, meta=env.meta, recipe_table=env.recipe_table, recipe_ids=env.recipe_ids[:n],
                    dims=env.dims, scheme=env.scheme_class.CODE, max_steps=env.max_steps,
                    end_condition_all=env.end_condition_all_dishes, num_recipes=env.num_recipes,
@@ -239,6 +275,10 @@ class ShardedOracle:
                                 num_recipes=env.num_recipes, reward_scheme=env.reward_scheme, pool_slices=env.pool_slices,
                                 env_level=env.env_level[lo:hi], num_envs=hi - lo, env_id_base=env.env_id_base + lo)
                       for lo, hi in self.spans]
+        if getattr(env, "spawn", None) is not None:
+            d, r, g, seed = env._spawn_cfg
+            for p in self.parts:
+                p.oracle.set_spawn(d, r, g, seed, env.spawn_cells, env.level_of_layout)
         self.num_envs, self.dims = n, env.dims
 
     def _each(self, fn):

@@ -1,5 +1,6 @@
 """GPU: randomised differential test of the HIP path against the oracle -- random level / scheme / agent count / recipe
-assignment / horizon / reward scheme / end condition per case, a fused rollout of T steps over the counter-based action
+assignment / horizon / reward scheme / end condition per case, and (round 4) despawn / respawn rates, a user recipe book with
+wide tables, a layout pool that is switched and refreshed mid-run; a fused rollout of T steps over the counter-based action
 stream, then final records, last observation and statistics must agree bit for bit.
 
 Default: a handful of cases (seconds).  CZ_FUZZ_CASES=N widens it for one-off soak runs (200 cases are about
@@ -33,20 +34,61 @@ def draw_case(i):
     if rng.random() < 0.5:
         reward = {"recipe_reward": float(rng.integers(1, 30)), "max_time_penalty": float(-rng.integers(0, 9)),
                   "recipe_penalty": float(-rng.integers(0, 50)), "recipe_node_reward": float(rng.integers(0, 4))}
-    return dict(level=level, meta_file=meta, num_agents=agents, recipes=recipes,
-                action_scheme="scheme3" if rng.random() < 0.6 else "scheme1", max_steps=int(rng.integers(5, 260)),
-                end_condition_all_dishes=bool(rng.random() < 0.3), reward_scheme=reward,
-                num_layouts=int(rng.integers(1, 40)), layout_seed=int(rng.integers(1 << 20))), int(rng.integers(1 << 30))
+    kw = dict(level=level, meta_file=meta, num_agents=agents, recipes=recipes,
+              action_scheme="scheme3" if rng.random() < 0.6 else "scheme1", max_steps=int(rng.integers(5, 260)),
+              end_condition_all_dishes=bool(rng.random() < 0.3), reward_scheme=reward,
+              num_layouts=int(rng.integers(1, 40)), layout_seed=int(rng.integers(1 << 20)))
+    seed = int(rng.integers(1 << 30))
+    # ---- the device paths of rounds 3 / 4 (drawn from a second stream, so that the cases above stay what they were)
+    rng2 = np.random.default_rng(77000 + i)
+    extra = {"wide": False, "rotate": False}
+    if rng2.random() < 0.4:                           # despawn / respawn inside the kernels (cz_set_spawn)
+        kw.update(agent_despawn_rate=float(rng2.choice([0.02, 0.1, 0.3])), agent_respawn_rate=float(rng2.choice([0.05, 0.25, 0.6])),
+                  grace_period=int(rng2.integers(0, 6)), spawn_seed=int(rng2.integers(1 << 40)))
+    if rng2.random() < 0.2:                           # a user recipe book with a 10-node graph: wide recipe tables
+        extra["wide"] = True
+        kw["recipes"] = [WIDE_BOOK[int(k)] for k in rng2.integers(len(WIDE_BOOK), size=len(recipes))]
+    if rng2.random() < 0.35:                          # the layout pool cut in two, switched and refreshed under the running batch
+        extra["rotate"] = True
+        kw["num_layouts"] = 2 * int(rng2.integers(1, 12))
+    extra["rng"] = rng2
+    return kw, seed, extra
+
+
+WIDE_BOOK = ["FruitFeast", "PickyBanana", "BreadSnack"]
+
+
+def fresh_layouts(env, count, rng):
+    """`count` newly instantiated layouts per level (the reference's draw order, engine/load_level.py)"""
+    import random
+    from cooking_zoo_amd.cooking_world.engine import load_level as ll
+    r = random.Random(int(rng.integers(1 << 30)))
+    return [[ll.instantiate(lv, env.meta, env.num_agents, r) for _ in range(count)] for lv in env.level_objects]
 
 
 @pytest.mark.parametrize("i", range(N_CASES))
 def test_random_configuration_matches_oracle(i):
-    kw, seed = draw_case(i)
+    kw, seed, extra = draw_case(i)
+    if extra["wide"]:
+        from cooking_zoo_amd.cooking_book import recipe_drawer as rd
+        from test_custom_recipes import register_fixture_recipes
+        assert not rd.RECIPE_STORE
+        register_fixture_recipes()
+    try:
+        run_case(i, kw, seed, extra)
+    finally:
+        if extra["wide"]:
+            rd.RECIPE_STORE.clear()
+
+
+def run_case(i, kw, seed, extra):
     n, T = 384, 480
     env = make(n, **kw)
     orc = oracle_for(env)
     env.reset(return_obs=False)
     orc.reset()
+    if extra["wide"]:
+        assert env.recipe_nodes == 16
     A = kw["num_agents"]
     chunk = T // 3
     d_rew = env.alloc((chunk, n, A), np.float64)
@@ -54,6 +96,17 @@ def test_random_configuration_matches_oracle(i):
     d_trunc = env.alloc((chunk, n, A), np.uint8)
     ctx = f"case {i}: {kw}"
     for t0 in range(0, T, chunk):                   # three launches: the state round-trips through HBM in between
+        if extra["rotate"] and t0 == chunk:         # from here the envs draw their next layouts from the second half of the pool
+            env.set_layout_group(2, 1)
+            orc.set_layout_group(2, 1)
+        if extra["rotate"] and t0 == 2 * chunk and kw["max_steps"] + 2 <= chunk:
+            # every episode that started on the first half is over: refresh it (cz_update_layouts) and go back to it
+            half = kw["num_layouts"] // 2
+            for (base, count), lays in zip(env.pool_slices, fresh_layouts(env, half, extra["rng"])):
+                env.update_layouts(base, lays)
+                orc.update_layouts(base, lays)
+            env.set_layout_group(2, 0)
+            orc.set_layout_group(2, 0)
         env.rollout(chunk, seed, t0, None, d_rew, d_term, d_trunc)
         env.sync()
         oo, ro, to, uo = orc.rollout(chunk, seed, t0)

@@ -1,6 +1,8 @@
 """Agent despawn / respawn evaluated by the step kernels (cz_set_spawn, Ops::handle_agent_spawn) against the host model
 (cooking_zoo_amd/spawn.py SpawnBook, and the scalar transliteration of the reference's rule in test_spawn_book.py) on top of
-the oracle: every stepping path - cz_step, cz_step_device, overlapped ring runs, cz_rollout - and shard invariance."""
+the oracle: every stepping path - cz_step, cz_step_device, overlapped ring runs, cz_rollout - and shard invariance; and
+against the oracle's own restatement of the rule (pinned to the reference by tests/golden/spawn_keyed_*.npz) on mixed-level
+batches (spawn areas per level) and on every kernel instance."""
 import ctypes as C
 
 import numpy as np
@@ -31,9 +33,10 @@ class Model:
     def __init__(self, env, scalar=False):
         from oracle_binding import VecOracle
         self.env, self.orc, self.scalar = env, VecOracle.from_vec_env(env), scalar
+        self.orc.oracle.set_spawn(0, 0, 0, 0, [])            # (the oracle's own rule off: this model does the bookkeeping itself)
         d, r, g, seed = env._spawn_cfg
         self.book = SpawnBook(env.num_envs, env.num_agents, env.spawn_cells, despawn_rate=d, respawn_rate=r, grace_period=g,
-                              seed=seed, env_id_base=env.env_id_base)
+                              seed=seed, env_id_base=env.env_id_base, level_of_layout=env.level_of_layout)
 
     def reset(self):
         self.book.reset_all()
@@ -173,3 +176,55 @@ def test_overlapped_ring_runs_do_the_same_bookkeeping():
     assert np.array_equal(bits(outs[0].to_host()), bits(o)) and np.array_equal(outs[3].to_host(), u)
     env.close()
     ref.close()
+
+
+@pytest.mark.parametrize("levels,meta,agents,recipes,scheme", [
+    (["coop_test", "coexistence_test", "switch_test"], "example", 2, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3"),      # config 3's shape
+    (["switch_test", "coop_test"], "example", 2, ["MashedCarrotBanana", "TomatoSalad"], "scheme1"),
+    (["large_16x16"], "large_16x16", 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"], "scheme3"),
+    (["large_16x16"], "large_16x16", 3, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon"], "scheme1"),
+    (["huge_objs_16x16"], "huge_objs_16x16", 3, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon"], "scheme3"),
+    (["huge_20x20"], "huge_20x20", 3, ["TomatoLettuceSalad", "MashedCarrotBanana", "TomatoSalad"], "scheme1"),            # one-cell areas: exhausted respawns
+    (["crowded_6x5"], "crowded_6x5", 1, ["TomatoSalad"], "scheme3"),                                                       # a lone agent never leaves
+])
+def test_spawning_batches_match_the_oracle_rule(levels, meta, agents, recipes, scheme):
+    """host-array steps, then a fused rollout, then a ring run, against the oracle (which evaluates the same keyed rule);
+    mixed levels take their spawn areas from each world's own level file (parsing.py:118-151)"""
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    from oracle_binding import VecOracle
+    n, A = 96, agents
+    kw = dict(action_scheme=scheme, num_layouts=6, auto_reset=True, agent_despawn_rate=0.12, agent_respawn_rate=0.3, grace_period=3, spawn_seed=21)
+    env = CookingVecEnv(n, levels if len(levels) > 1 else levels[0], meta, A, 35, recipes, env_id_base=500, **kw)
+    # (env e of a batch plays level e % len(levels): halves of 48 envs keep that assignment for 1, 2 and 3 levels)
+    parts = [CookingVecEnv(n // 2, levels if len(levels) > 1 else levels[0], meta, A, 35, recipes, env_id_base=500 + k * (n // 2), **kw) for k in range(2)]
+    orc = VecOracle.from_vec_env(env)
+    og, oo = env.reset(), orc.reset()
+    [p.reset(return_obs=False) for p in parts]
+    assert np.array_equal(bits(og), bits(oo)) and np.array_equal(strip(env.get_state()), orc.records)
+    rng = np.random.default_rng(8)
+    n_gone_seen = 0
+    for t in range(60):
+        acts = rng.integers(0, env.n_actions, size=(n, A), dtype=np.int32)
+        og, rg, tg, ug = env.step(acts)
+        oo, ro, to, uo = orc.step(acts)
+        [p.step(acts[k * (n // 2):(k + 1) * (n // 2)], return_obs=False) for k, p in enumerate(parts)]
+        assert np.array_equal(bits(og), bits(oo)), f"observation at step {t}"
+        assert np.array_equal(bits(rg), bits(ro)) and np.array_equal(tg, to) and np.array_equal(ug, uo), f"rewards / flags at step {t}"
+        assert np.array_equal(strip(env.get_state()), orc.records), f"records at step {t}"
+        gone = (orc.records[:, soa.W_STATUS] >> 8) & 0xF
+        n_gone_seen += int((gone != 0).sum())
+        assert (np.array([bin(int(g)).count("1") for g in gone]) < max(A, 2)).all()          # never everybody
+    T = 50
+    d_obs, d_u = env.alloc((T, n, A, env.F), np.float64), env.alloc((T, n, A), np.uint8)
+    env.rollout(T, 9, 1000, d_obs, None, None, d_u)
+    [p.rollout(T, 9, 1000) for p in parts]
+    env.sync()
+    oo, ro, to, uo = orc.rollout(T, 9, 1000)
+    assert np.array_equal(strip(env.get_state()), orc.records) and np.array_equal(bits(d_obs.to_host()[-1]), bits(oo))
+    assert np.array_equal(d_u.to_host()[-1], uo)
+    assert np.array_equal(strip(env.get_state()), np.concatenate([strip(p.get_state()) for p in parts])), "shard invariance"
+    assert (n_gone_seen > 100) if A > 1 else (n_gone_seen == 0)       # (a lone agent never leaves: cooking_world.py:273)
+    if levels == ["huge_20x20"]:
+        assert env.spawn_exhausted() > 0
+    env.close()
+    [p.close() for p in parts]

@@ -42,7 +42,7 @@ def test_vectorised_bookkeeping_equals_the_scalar_rule():
         soa.record_cells(dims, recs[e])[:] = cells
         for a in range(A):
             recs[e, soa.AGENT_WORD0 + a] = soa.pack_agent(a, 0, 1, -1)
-    spawn_cells = [([1, 2, 3, 4], [1, 2, 3])] * A
+    spawn_cells = [[([1, 2, 3, 4], [1, 2, 3])] * A]
     book = SpawnBook(N, A, spawn_cells, despawn_rate=0.3, respawn_rate=0.4, grace_period=2, seed=7, env_id_base=1000)
     twins = [dict(active=[True] * A, changed=[False] * A, grace=[2] * A, seed=7, despawn=0.3, respawn=0.4, grace_period=2) for _ in range(N)]
     saw_despawn = saw_respawn = saw_holding_stay = 0
@@ -69,7 +69,7 @@ def test_vectorised_bookkeeping_equals_the_scalar_rule():
                 if book.changed[e, a] and book.active[e, a]:
                     saw_respawn += 1
                     x, y, _, _ = soa.unpack_agent(recs[e, soa.AGENT_WORD0 + a])
-                    assert x in spawn_cells[a][0] and y in spawn_cells[a][1]
+                    assert x in spawn_cells[0][a][0] and y in spawn_cells[0][a][1]
                     others = [soa.unpack_agent(recs[e, soa.AGENT_WORD0 + b])[:2] for b in range(A) if b != a]
                     assert (x, y) not in others
     assert saw_despawn > 500 and saw_respawn > 500

@@ -506,6 +506,156 @@ def capture_spawn_episode(cfg, seed, policy_name, rates, max_len=None):
     }
 
 
+def action_hash(seed, env_global, agent, step, n):
+    """the device's counter-based action stream (csrc/cz_device.h action_hash, oracle czo_action), restated for the generator;
+    tests/test_spawn_keyed.py checks it against the oracle's"""
+    M = 0xFFFFFFFF
+    x = (seed & M) ^ (((seed >> 32) * 0x9E3779B1) & M)
+    x ^= ((env_global & M) * 0x85EBCA6B + ((env_global >> 32) & M) * 0x27D4EB2F) & M
+    x ^= ((agent + 1) * 0xC2B2AE35) & M
+    x ^= ((step + 1) * 0x165667B1) & M
+    for rnd in range(2):
+        if rnd:
+            x = (x + step * 0x9E3779B9) & M
+        x ^= x >> 16; x = (x * 0x7FEB352D) & M; x ^= x >> 15; x = (x * 0x846CA68B) & M; x ^= x >> 16
+    return (x * n) >> 32
+
+
+def capture_spawn_keyed_episode(cfg, seed, policy_name, rates, env_id, episode_no, spawn_seed, max_len=None):
+    """One episode of the UNMODIFIED reference with despawn / respawn on, in which every draw the reference takes inside
+    `CookingWorld.handle_agent_spawn` (np.random.random, cooking_world.py:273-276) and `parsing.generate_location`
+    (random.sample, parsing.py:157-158) is answered with the batched build's keyed stream
+    `spawn.uniform(spawn_seed, env_id, episode_no << 32 | t, agent, draw)`: draw 0 = the despawn test, 1 = the respawn test,
+    2 + 2 k / 3 + 2 k = the x / y candidate of try k.  Which agent and which try a call belongs to is read from the calling
+    frames of the reference's own functions (the loop variable `i`, `index`, `time_out`) - nothing of the reference is replaced
+    but the two random sources.  The fixture is what a batched env with the same key must reproduce: records incl. the status
+    word (despawned bits, grace counters), observations of every agent, per-recipe rewards, flags incl. the truncated-once
+    report of an agent that leaves.  policy "stream": actions from the device's own counter-based stream (cz_rollout)."""
+    import numpy.random as npr
+    from cooking_zoo_amd import spawn as czspawn
+    random.seed(seed)
+    np.random.seed(seed)
+    rng = np.random.default_rng(seed + 7919)
+    despawn, respawn, grace = rates
+    env = CookingEnvironment(level=cfg["level"], meta_file=cfg["meta_file"], num_agents=cfg["num_agents"],
+                             max_steps=cfg["max_steps"], recipes=cfg["recipes"],
+                             obs_spaces=["feature_vector"] * cfg["num_agents"],
+                             end_condition_all_dishes=cfg["end_condition_all_dishes"],
+                             action_scheme=cfg["action_scheme"], reward_scheme=cfg.get("reward_scheme"),
+                             agent_respawn_rate=respawn, grace_period=grace, agent_despawn_rate=despawn)
+    env.reset()
+    world = env.world
+    A = cfg["num_agents"]
+    F = env.feature_vector_representation_length
+    D = cfg["max_dyn"]
+    dims = soa.Dims(world.width, world.height, D, A, F)
+    slotmap = SlotMap(world, D)
+    recipe_ids = [RECIPE_NAMES.index(r) for r in cfg["recipes"]]
+    scheme = cfg["action_scheme"]
+    n_act = 5 if scheme == "scheme3" else 8
+    pols = [Bumper(rng, scheme) if (policy_name == "bumper" or (policy_name == "mixed" and i % 2)) else Uniform(rng, scheme)
+            for i in range(A)]
+    log = {"draws": 0, "tries": 0, "respawns": 0}
+    st = {"calls": 0}
+
+    def key():
+        return (episode_no << 32) | env.t                    # (accumulated_step has already incremented t: cooking_env.py:244)
+
+    def keyed_random():
+        fr = sys._getframe(1)
+        assert fr.f_code.co_name == "handle_agent_spawn", fr.f_code.co_name
+        i, w = fr.f_locals["i"], fr.f_locals["self"]
+        log["draws"] += 1
+        return float(czspawn.uniform(spawn_seed, env_id, key(), i, 0 if w.active_agents[i] else 1))
+
+    def keyed_sample(population, k):
+        fr = sys._getframe(1)
+        assert fr.f_code.co_name == "generate_location" and k == 1, fr.f_code.co_name
+        up = sys._getframe(2)
+        assert up.f_code.co_name == "respawn_agent"
+        agent, time_out = up.f_locals["index"], fr.f_locals["time_out"]
+        axis = st["calls"] % 2
+        assert st["calls"] // 2 == time_out, (st["calls"], time_out)      # two samples per try: x, then y
+        st["calls"] += 1
+        log["tries"] += axis
+        u = float(czspawn.uniform(spawn_seed, env_id, key(), agent, 2 + 2 * time_out + axis))
+        return [population[int(u * len(population))]]
+
+    orig_spawn, orig_respawn, orig_rewards = world.handle_agent_spawn, world.respawn_agent, env.compute_rewards
+    snap = {}
+
+    def respawn_hook(index):
+        st["calls"] = 0
+        log["respawns"] += 1
+        return orig_respawn(index)
+
+    def spawn_hook():
+        keep = (npr.random, np.random.random, random.sample)
+        np.random.random = keyed_random
+        random.sample = keyed_sample
+        try:
+            orig_spawn()
+        finally:
+            np.random.random, random.sample = keep[1], keep[2]
+
+    def rewards_hook(*args, **kw):
+        out = orig_rewards(*args, **kw)
+        snap["dones"], snap["rewards"] = out[0], out[1]
+        return out
+    world.handle_agent_spawn = spawn_hook
+    world.respawn_agent = respawn_hook
+    env.compute_rewards = rewards_hook
+
+    def record():
+        rec = world_to_record(env, dims, slotmap, 0, recipe_ids)
+        rec[soa.W_EPISODE] = episode_no
+        rec[soa.W_STATUS] |= czspawn.status_bits(np.array([world.active_agents], dtype=bool),
+                                                 np.array([world.agent_grace_period], dtype=np.int64))[0]
+        return rec
+
+    full_obs = lambda: np.stack([env.get_feature_vector(a) for a in env.possible_agents])
+    states, obs = [record()], [full_obs()]
+    actions, rewards, terms, truncs = [], [], [], []
+    limit = max_len or cfg["max_steps"]
+    for step in range(limit):
+        act_now = list(world.active_agents)
+        if policy_name == "stream":
+            full = [action_hash(spawn_seed, env_id, i, step, n_act) for i in range(A)]
+        else:
+            # (a despawned agent gets an action too: the batched env must ignore it by itself)
+            full = [pols[i].act(world, i) if act_now[i] else int(rng.integers(0, n_act)) for i in range(A)]
+        try:
+            env.accumulated_step([a for i, a in enumerate(full) if act_now[i]])
+        except IndexError:
+            # reference defect (cooking_env.py:337): max_steps reached while somebody is despawned; the build truncates instead
+            assert env.t >= cfg["max_steps"] and not all(act_now)
+            break
+        gone = [bool(world.status_changed[i] and not world.active_agents[i]) for i in range(A)]
+        trunc_all = env.t >= cfg["max_steps"]
+        if trunc_all:
+            break                     # (compute_truncated has cleared active_agents: the step's spawn bookkeeping is not what a record holds)
+        actions.append(full)
+        rewards.append([float(snap["rewards"][i]) for i in range(A)])
+        terms.append([bool(snap["dones"][0])] * A)
+        truncs.append([bool(g) for g in gone])
+        rec = record()
+        if terms[-1][0]:
+            rec[soa.W_STATUS] |= 1 | 2                                     # done | terminated (cz_device.h ST_*)
+        states.append(rec)
+        obs.append(full_obs())
+        if terms[-1][0]:
+            break
+    return {
+        "dims": np.array(dims.as_tuple(), dtype=np.int32), "states": np.stack(states), "obs": np.stack(obs),
+        "actions": np.array(actions, dtype=np.int32).reshape(-1, A),
+        "rewards": np.array(rewards, dtype=np.float64).reshape(-1, A),
+        "terms": np.array(terms, dtype=np.uint8).reshape(-1, A), "truncs": np.array(truncs, dtype=np.uint8).reshape(-1, A),
+        "statics": static_lists(env), "class_order": slotmap.class_order,
+        "spawn_areas": [[list(xs), list(ys)] for xs, ys in world.agent_spawn_locations],
+        "log": dict(log),
+    }
+
+
 def episode_stats(ep):
     """Coverage summary of what an episode reached (for the generator log)."""
     dims = soa.Dims(*[int(v) for v in ep["dims"]])
@@ -540,6 +690,9 @@ def save_set(name, cfg, episodes, out_dir):
                 arrays[f"e{i}_{k}"] = ep[k]
         meta["episodes"].append({"statics": ep["statics"], "class_order": ep["class_order"],
                                  "seed": ep["seed"], "policy": ep["policy"] if isinstance(ep["policy"], str) else "scripted"})
+        for k in ("env_id", "episode_no", "spawn_areas"):                   # keyed despawn / respawn sets only
+            if k in ep:
+                meta["episodes"][-1][k] = ep[k]
     arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     path = os.path.join(out_dir, name + ".npz")
     np.savez_compressed(path, **arrays)
@@ -697,6 +850,48 @@ def main():
             "spawn_crowded_scheme1",
             base_cfg(crowd, 3, ["TomatoSalad", "TomatoLettuceSalad", "MashedCarrotBanana"], scheme="scheme1", max_steps=120, meta=metac),
             [(320, "bumper", 120), (321, "uniform", 120)], (0.1, 0.2, 3))
+    # despawn / respawn with KEYED draws (capture_spawn_keyed_episode): what the batched env evaluates on the device, produced by
+    # the reference's own handle_agent_spawn / generate_location.  plan entries: (seed, policy, max_len, env id, episode number)
+    def keyed_set(name, cfg, plan, rates, spawn_seed):
+        eps = []
+        for seed, policy, max_len, env_id, episode_no in plan:
+            ep = capture_spawn_keyed_episode(cfg, seed, policy, rates, env_id, episode_no, spawn_seed, max_len)
+            ep["seed"], ep["policy"], ep["env_id"], ep["episode_no"] = seed, policy, env_id, episode_no
+            gone = int(ep["truncs"].sum())
+            print(f"   {name} seed={seed} policy={policy} env={env_id} episode={episode_no}: {episode_stats(ep)} left {gone} {ep['log']}")
+            eps.append(ep)
+        cfg = dict(cfg, rates=list(rates), spawn_seed=spawn_seed)
+        return save_set(name, cfg, eps, args.out)
+    lv = lambda n: os.path.join(REPO, "cooking_zoo_amd", "utils", "level", n + ".json")
+    mt = lambda n: os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", n + ".json")
+    four = ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"]
+    sets["spawn_keyed_coop_2agents"] = lambda: keyed_set(
+        "spawn_keyed_coop_2agents", base_cfg("coop_test", 2, ["TomatoLettuceSalad", "CarrotBanana"], max_steps=400),
+        [(900, "bumper", 160, 0, 0), (901, "uniform", 160, 7, 3), (902, "stream", 200, 4100, 1), (903, "stream", 200, 1 << 33, 65536)], (0.15, 0.3, 2), 11)
+    sets["spawn_keyed_crowded_4agents"] = lambda: keyed_set(
+        "spawn_keyed_crowded_4agents",
+        base_cfg(lv("crowded_6x5"), 4, ["TomatoSalad", "TomatoLettuceSalad", "no_recipe", "MashedCarrotBanana"], max_steps=400, meta=mt("crowded_6x5")),
+        [(910, "bumper", 200, 1, 0), (911, "uniform", 200, 2, 5), (912, "mixed", 200, 3, 2), (913, "stream", 250, 40, 9)], (0.2, 0.25, 1), 5)
+    sets["spawn_keyed_crowded_scheme1"] = lambda: keyed_set(
+        "spawn_keyed_crowded_scheme1",
+        base_cfg(lv("crowded_6x5"), 3, ["TomatoSalad", "TomatoLettuceSalad", "MashedCarrotBanana"], scheme="scheme1", max_steps=400, meta=mt("crowded_6x5")),
+        [(920, "bumper", 160, 11, 0), (921, "uniform", 160, 12, 1), (922, "stream", 200, 13, 4)], (0.1, 0.2, 3), 77)
+    sets["spawn_keyed_large16_4agents"] = lambda: keyed_set(
+        "spawn_keyed_large16_4agents", base_cfg(lv("large_16x16"), 4, four, max_steps=400, meta=mt("large_16x16")),
+        [(930, "bumper", 160, 21, 0), (931, "mixed", 160, 22, 6), (932, "stream", 200, 23, 1)], (0.2, 0.3, 2), 123456789)
+    sets["spawn_keyed_large16_scheme1"] = lambda: keyed_set(
+        "spawn_keyed_large16_scheme1", base_cfg(lv("large_16x16"), 2, four[:2], scheme="scheme1", max_steps=400, meta=mt("large_16x16")),
+        [(940, "bumper", 120, 31, 0), (941, "stream", 160, 32, 2)], (0.25, 0.4, 0), 3)
+    # (the third kernel instance: huge_objs_16x16, 190 object slots.  huge_20x20 / huge_32x32 give two agents a one-cell spawn
+    # area, which the despawned agent itself occupies: the reference's generate_location raises there)
+    sets["spawn_keyed_hugeobjs_3agents"] = lambda: keyed_set(
+        "spawn_keyed_hugeobjs_3agents",
+        base_cfg(lv("huge_objs_16x16"), 3, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon"], max_steps=400, meta=mt("huge_objs_16x16")),
+        [(950, "bumper", 120, 41, 0), (951, "stream", 160, 42, 3)], (0.2, 0.35, 1), 99)
+    sets["spawn_keyed_hugeobjs_scheme1"] = lambda: keyed_set(
+        "spawn_keyed_hugeobjs_scheme1",
+        base_cfg(lv("huge_objs_16x16"), 2, ["TomatoLettuceSalad", "CarrotBanana"], scheme="scheme1", max_steps=400, meta=mt("huge_objs_16x16")),
+        [(960, "uniform", 100, 51, 0), (961, "stream", 120, 52, 1)], (0.3, 0.5, 2), 8)
     dense = os.path.join(REPO, "cooking_zoo_amd", "utils", "level", "dense_16x16.json")
     metad = os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", "dense_16x16.json")
     if os.path.exists(dense) and os.path.exists(metad):
