@@ -194,6 +194,61 @@ def leg_closed_loop(env, d_obs, d_rew, d_term, d_trunc):
                                        "HIP events around graph replays of the closed loop; step + policy kernel + both boundaries")}
 
 
+def leg_closed_loop_compact(env, d_rew, d_term, d_trunc):
+    """The same closed loop for a consumer that stays on the device and reads the COMPACT observation (cz_step_device_compact:
+    one byte per feature = the index of its value in a table of 256 float64, bit-exactly decodable): the step kernel writes
+    N x A x pitch bytes instead of N x A x F x 8, the policy kernel reads the same four features as table indices and takes the same
+    actions.  Roofline on ITS algorithmic bytes (the code bytes instead of the float64 rows)."""
+    from cooking_zoo_amd import _native
+    L, h = _native.lib(), env._h
+    N, A = env.num_envs, env.num_agents
+    d_act = env.alloc((N, A), np.int32)
+    d_act.from_host(np.random.default_rng(7).integers(0, env.n_actions, size=(N, A), dtype=np.int32))
+    d_codes = env.alloc((N, A, env.codes_pitch), np.uint8)
+    K, reps = 200, 10
+    us = C.c_float()
+    s0 = env.stats()["env_steps"]
+    try:
+        _native.check(h, L.cz_probe_closed_loop_compact(h, K, reps, d_act.ptr, d_codes.ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr, C.byref(us)))
+        stepped = (env.stats()["env_steps"] - s0) / float(N * K * (reps + 1))
+    finally:
+        d_act.free()
+        d_codes.free()
+    b_alg = algorithmic_bytes_per_env_step(env) - A * 8 * env.F + A * env.F        # one byte per feature instead of eight
+    return {"env_steps_per_s": stepped * N / (us.value * 1e-6), "us_per_step": us.value, "envs": N, "obs_bytes_per_env_step": A * env.codes_pitch,
+            "what": "closed loop on one stream over the compact observation: cz_step_device_compact (uint8 code per feature, table of 256 "
+                    f"float64 resident; no float64 rows written) -> policy kernel reading the codes -> ...; {K}-step HIP graph replayed {reps} times",
+            "roofline": roofline_block(b_alg, N, us.value, "cz::k_step<1,1,2,3,0> (codes only) + k_probe_policy_codes per step",
+                                       "HIP events around graph replays; algorithmic bytes with 1 byte per feature")}
+
+
+def leg_fused_actions(env, K):
+    """T = 32 fused steps per launch over actions of the CALLER (cz_rollout_actions: replay / open-loop search), float64
+    trajectory [T][N][A][F]"""
+    N, A, T = env.num_envs, env.num_agents, 32
+    d_traj = env.alloc((T, N, A, env.F), np.float64)
+    d_act = env.alloc((T, N, A), np.int32)
+    try:
+        d_act.from_host(np.random.default_rng(11).integers(0, env.n_actions, size=(T, N, A), dtype=np.int32))
+        reps = max(2, min(K, 2000) // T)
+        env.rollout_actions(d_act, T, d_traj)
+        env.sync()
+        f0 = env.stats()["env_steps"]
+        t0 = time.perf_counter()
+        for r in range(reps):
+            env.rollout_actions(d_act, T, d_traj)
+        env.sync()
+        dt = time.perf_counter() - t0
+        out = {"env_steps_per_s_per_gpu": (env.stats()["env_steps"] - f0) / dt, "steps_per_launch": T, "ms_per_step": dt * 1e3 / (reps * T),
+               "api": "cz_rollout_actions: int32 actions [T][N][A] of the caller in HBM, obs trajectory [T][N][A][F]"}
+        out["roofline"] = roofline_block(algorithmic_bytes_per_env_step(env), N, out["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,2> (32 steps per launch)",
+                                         "wall clock around the cz_rollout_actions launches")
+        return out
+    finally:
+        d_traj.free()
+        d_act.free()
+
+
 def cooking_policy_workload(device_id, K=512):
     """The one-step kernel under a policy that cooks: the reference's heuristic agent's action sequences (golden fixtures
     cfg2_coop_2agents, episodes that end with a delivered dish), every env on one of those worlds at its own phase of the
@@ -719,7 +774,9 @@ def worker_body(args, rdzv, overlap, note):
         if world == 1 and not args.no_extras and not args.no_obs:
             # what users get beside the open-loop headline; each leg a fraction of a second of GPU time.
             # An extra leg must never be able to lose the headline measured above: whatever it raises is recorded under its key.
+            line["fused_actions"] = guarded(leg_fused_actions, env, K)
             line["closed_loop"] = guarded(leg_closed_loop, env, d_obs, d_rew, d_term, d_trunc)
+            line["closed_loop_compact"] = guarded(leg_closed_loop_compact, env, d_rew, d_term, d_trunc)
             line["cooking_policy"] = guarded(leg_cooking_policy, local_rank)
             line["configs"] = guarded(leg_configs, local_rank)
         if world == 1 and not args.no_cpu_baseline:

@@ -61,6 +61,12 @@ SYMBOLS = [
     ("cz_observe", C.c_int, [_VP, _I64, _I64, _VP]),
     ("cz_step", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     ("cz_step_device", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    ("cz_step_device_compact", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    ("cz_set_compact_output", C.c_int, [_VP, _VP]),
+    ("cz_codes_pitch", _I32, [_VP]),
+    ("cz_obs_table", C.c_int, [_VP, _VP]),
+    ("cz_obs_table_device", _VP, [_VP]),
+    ("cz_probe_closed_loop_compact", C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, C.POINTER(C.c_float)]),
     ("cz_step_device_many", C.c_int, [_VP, _I32, _VP, _I64, _I32, _VP, _VP, _VP, _VP]),
     ("cz_step_device_ring", C.c_int, [_VP, _I32, _VP, _I64, _I32, _I32, _VP, _VP, _VP, _VP]),
     ("cz_ring_prepare", C.c_int, [_VP, _I32, _VP, _I64, _I32, _I32, _VP, _VP, _VP, _VP]),

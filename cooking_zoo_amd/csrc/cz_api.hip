@@ -122,6 +122,19 @@ __global__ void k_probe_policy(const double *__restrict__ obs, int32_t *__restri
     actions[row] = (int32_t)(((x & 0xFFFFFFFFull) * n_actions) >> 32);
 }
 
+// ... the same policy for a consumer of the COMPACT observation (cz_step_device_compact): the four features come as table
+// indices, the table turns them into the very doubles k_probe_policy reads - so both loops take the same actions
+__global__ void k_probe_policy_codes(const uint8_t *__restrict__ codes, const double *__restrict__ table, int32_t *__restrict__ actions,
+                                     int n_rows, int F, int Fp, uint32_t n_actions) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;               // (env, agent)
+    if (row >= n_rows) return;
+    const uint8_t *c = codes + (size_t)row * Fp;
+    const unsigned long long *t = reinterpret_cast<const unsigned long long *>(table);
+    unsigned long long x = t[c[0]] ^ (t[c[F / 3]] * 3ull) ^ (t[c[(2 * F) / 3]] * 5ull) ^ (t[c[F - 1]] * 7ull) ^ ((unsigned long long)row << 17);
+    x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33;
+    actions[row] = (int32_t)(((x & 0xFFFFFFFFull) * n_actions) >> 32);
+}
+
 // cz_load_layouts with a smaller pool: how many resident records still point past the new pool (layout id or redraw slice)
 __global__ void k_layout_misfits(const uint32_t *__restrict__ state, int RW, int N, uint32_t n_new, unsigned long long *count) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -178,6 +191,7 @@ struct cz_handle_s {
     cz_stats *d_stats_out = nullptr;
     unsigned long long *d_stats_part = nullptr;   // [256 chains][16 columns] between the two stages of the reduction
     double *d_lut = nullptr;
+    double obs_table[LUT_SIZE];        // host copy of the quotient table (cz_obs_table: what the compact observation's codes index)
     int32_t *d_reset_words = nullptr;  // [3][N]: layout ids, recipe words, pool words of a cz_reset call
     void *d_dump = nullptr;            // [N][4] doubles: where a one-step launch writes an output array the caller passed as NULL
     // staging for the host-pointer API
@@ -360,13 +374,17 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     P.recipe_reward = cfg->recipe_reward; P.recipe_penalty = cfg->recipe_penalty; P.node_reward = cfg->recipe_node_reward;
     P.time_penalty_step = cfg->max_time_penalty / (double)cfg->max_steps;       // cooking_env.py:307
     P.T = 1;
+#ifdef CZ_ABLATE
     P.stop = -1;
+#endif
     if (const char *s = getenv("CZ_WT")) h->wt_override = atoi(s);
     if (const char *s = getenv("CZ_GRAPHS")) h->graphs_enabled = atoi(s) != 0;
     h->chain_wanted_by_env = getenv("CZ_CHAIN") && atoi(getenv("CZ_CHAIN")) != 0;
     if (const char *s = getenv("CZ_RING_PREFIX")) h->ring_prefix = atoi(s) < 0 ? 0 : (atoi(s) > 16 ? 16 : atoi(s));
     if (const char *s = getenv("CZ_ZERO_COPY_BYTES")) h->zero_copy_bytes = (size_t)atoll(s);
-    if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // honoured by the ablation build only
+#ifdef CZ_ABLATE
+    if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // (the ablation build only: make ablate)
+#endif
 #ifdef CZ_SMALL_ONLY       // diagnostic libraries that carry the small instance only
     if (!(P.D <= 64 && C <= 64)) { fail(nullptr, "cz_create: this diagnostic library holds the small kernel instance only"); cz_destroy(h); return 1; }
     h->kl = launchers_small();
@@ -457,13 +475,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
         CREATE_CHK(hipMemcpy(h->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
         CREATE_CHK(hipMemcpy((char *)h->d_lut + sizeof lut, submask, sizeof submask, hipMemcpyHostToDevice));
         P.lut = h->d_lut;
-        P.inv_w = (65536u + (uint32_t)P.W - 1u) / (uint32_t)P.W;
-        for (uint32_t c = 0; c < 1024; ++c)
-            if (((c * P.inv_w) >> 16) != c / (uint32_t)P.W) {
-                fail(nullptr, "cz_create: internal: inexact cell division for W=%d", P.W);
-                cz_destroy(h);
-                return 1;
-            }
+        memcpy(h->obs_table, lut, sizeof lut);
     }
 #undef CREATE_CHK
     if (h->chain_wanted_by_env) (void)cz_set_overlap(h, 1);       // (stays off if another handle of the device has it)
@@ -959,7 +971,7 @@ static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr, boo
 // can this launch be part of an overlapped run?  (one-step kernel with write-through observation stores: two waves of
 // different launches write the same output bytes, so those must not sit dirty in two L2s)
 static bool chainable(cz_handle h, const Params &P) {
-    if (!h->chain_enabled || h->ktime || !P.actions || P.N > h->chain_max_envs) return false;
+    if (!h->chain_enabled || h->ktime || !P.actions || P.codes || P.N > h->chain_max_envs) return false;      // (no compact output in overlapped runs)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;   // a caller's capture
     if (h->wt_override >= 0) return h->wt_override == 1;
@@ -1068,6 +1080,33 @@ extern "C" int cz_step_device(cz_handle h, const int32_t *d_actions, double *d_o
     P.marks_out = h->marks_out_next; h->marks_out_next = nullptr;
     return launch_step(h, P);
 }
+
+// The step with the observation as one byte per feature (and, optionally, the float64 one beside it): see observe() in cz_kernels.h.
+extern "C" int cz_step_device_compact(cz_handle h, const int32_t *d_actions, uint8_t *d_codes, double *d_obs, double *d_rewards,
+                                      uint8_t *d_term, uint8_t *d_trunc) {
+    if (ready(h)) return 1;
+    if (!d_actions || !d_codes) return fail(h, "cz_step_device_compact: actions and codes pointers must not be null");
+    if (set_device(h)) return 1;
+    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;
+    Params P = h->P;
+    P.actions = d_actions; P.obs = d_obs; P.codes = d_codes; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
+    return launch_step(h, P);
+}
+// From now on EVERY one-step launch of the handle (cz_step_device, _many, _ring, cz_step) also writes the compact observation
+// to d_codes (uint8 [N][A][pitch]); NULL switches it off.  With d_obs = NULL in those calls the launches write codes only.
+extern "C" int cz_set_compact_output(cz_handle h, uint8_t *d_codes) {
+    if (!h) return fail(nullptr, "null handle");
+    h->P.codes = d_codes;
+    h->tables_version++;                  // (graphs captured for the ring carry the pointer)
+    return 0;
+}
+extern "C" int32_t cz_codes_pitch(cz_handle h) { return h ? codes_pitch(h->P.F) : 0; }
+extern "C" int cz_obs_table(cz_handle h, double *table) {
+    if (!h || !table) return fail(h, "cz_obs_table: null argument");
+    memcpy(table, h->obs_table, sizeof h->obs_table);
+    return 0;
+}
+extern "C" const void *cz_obs_table_device(cz_handle h) { return h ? (const void *)h->d_lut : nullptr; }
 
 // K consecutive steps, one launch each, issued from C: step k reads actions d_actions + k * action_stride (int32 units,
 // wrapping every `action_period` steps) and overwrites the same output buffers.  Same work as K cz_step_device calls
@@ -1448,7 +1487,49 @@ extern "C" int cz_probe_closed_loop(cz_handle h, int32_t K, int32_t reps, int32_
     int bad = 0;
     for (int k = 0; k < K && !bad; ++k) {
         bad = launch_step(h, P);
-        if (!bad) hipLaunchKernelGGL(k_probe_policy, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, d_obs, d_actions, rows, h->P.F, n_actions);
+        if (!bad && !getenv("CZ_PROBE_NO_POLICY")) hipLaunchKernelGGL(k_probe_policy, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, d_obs, d_actions, rows, h->P.F, n_actions);
+    }
+    const hipError_t ec = hipStreamEndCapture(h->stream, &g);
+    h->ktime = was_timing;
+    if (bad) { if (g) (void)hipGraphDestroy(g); return 1; }
+    HIPCHK(h, ec);
+    const hipError_t ei = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIPCHK(h, ei);
+    hipError_t rc = hipGraphLaunch(ge, h->stream);                         // warm
+    if (rc == hipSuccess) rc = hipEventRecord(h->ev0, h->stream);
+    for (int r = 0; r < reps && rc == hipSuccess; ++r) rc = hipGraphLaunch(ge, h->stream);
+    if (rc == hipSuccess) rc = hipEventRecord(h->ev1, h->stream);
+    if (rc == hipSuccess) rc = hipEventSynchronize(h->ev1);
+    float ms = 0.f;
+    if (rc == hipSuccess) rc = hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    (void)hipGraphExecDestroy(ge);
+    HIPCHK(h, rc);
+    *us_per_step = ms * 1e3f / (float)((int64_t)reps * K);
+    return 0;
+}
+
+// ... the same closed loop for a consumer of the compact observation: cz_step_device_compact (codes only, no float64 rows), then
+// the policy kernel that reads the codes
+extern "C" int cz_probe_closed_loop_compact(cz_handle h, int32_t K, int32_t reps, int32_t *d_actions, uint8_t *d_codes, double *d_rewards,
+                                            uint8_t *d_term, uint8_t *d_trunc, float *us_per_step) {
+    if (ready(h)) return 1;
+    if (K < 1 || K > 1024 || reps < 1 || !d_actions || !d_codes || !us_per_step) return fail(h, "cz_probe_closed_loop_compact: bad arguments");
+    if (set_device(h)) return 1;
+    Params P = h->P;
+    P.actions = d_actions; P.obs = nullptr; P.codes = d_codes; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
+    const int rows = h->P.N * h->P.A;
+    const uint32_t n_actions = h->P.scheme == 3 ? 5u : 8u;
+    const bool was_timing = h->ktime;
+    h->ktime = false;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int bad = 0;
+    for (int k = 0; k < K && !bad; ++k) {
+        bad = launch_step(h, P);
+        if (!bad && !getenv("CZ_PROBE_NO_POLICY")) hipLaunchKernelGGL(k_probe_policy_codes, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, d_codes, h->d_lut, d_actions, rows,
+                                     h->P.F, codes_pitch(h->P.F), n_actions);
     }
     const hipError_t ec = hipStreamEndCapture(h->stream, &g);
     h->ktime = was_timing;

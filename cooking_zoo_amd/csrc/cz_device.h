@@ -64,6 +64,7 @@ struct Params {
     double *rewards;               // [N][A] / [T][N][A] / nullptr
     uint8_t *term, *trunc;         // likewise
     uint32_t *marks_out;           // [N] recipe-node marks after the step (host-pointer cz_step only), or nullptr
+    uint8_t *codes;                // [N][A][Fp] compact observation (cz_step_device_compact): one table index per feature, or nullptr
     uint32_t *stat_u;              // [N][SU_WORDS]
     double *stat_f;                // [N][SF_WORDS]
     int64_t env_id_base;
@@ -71,7 +72,6 @@ struct Params {
     double recipe_reward, recipe_penalty, node_reward, time_penalty_step;
     double reward_idle;            // the reward formula evaluated with no goal change (host, same op order)
     const double *lut;             // [256] host-computed quotients: [i] (i-(W-1))/W, [63+i] (i-(H-1))/H, [126] 0, [127] 1, rest 0
-    uint32_t inv_w;                // ceil(65536 / W): c / W == (c * inv_w) >> 16 for every cell index c
     int32_t N, A, W, H, D, F, RW, scheme, max_steps, end_all, R, auto_reset, L;
     int32_t T;                     // fused steps per launch (1 for cz_step)
     uint32_t step0;
@@ -79,7 +79,9 @@ struct Params {
     int32_t wt;                    // 1: observation stores are write-through (sc1); chosen per launch by the host
     int32_t walk_touches;          // 1 if carrying an object across cells can change a recipe mark (see cz_load_recipes)
     int32_t wide;                  // 1: wide recipe tables (up to 16 nodes per graph, marks in record words 1 and 7)
-    int32_t stop;                  // ablation build only: phase index after which the kernel returns (CZ_STOP), else -1
+#ifdef CZ_ABLATE
+    int32_t stop, stop_pad;        // ablation build only: phase index after which the kernel returns (CZ_STOP), else -1
+#endif
     // (the argument block is 56 + 264 bytes = five 64-byte lines exactly; one more field costs every launch a sixth)
 #ifdef CZ_PROFILE
     unsigned long long *stamps;    // diagnostic build only: [N][8] s_memtime stamps (that build does not overlap launches)
@@ -91,7 +93,7 @@ struct Params {
     unsigned long long *timeline;  // timeline build only (make timeline): [N][2] entry / exit stamps of this launch's waves, or nullptr
 #endif
 };
-#ifndef CZ_TIMELINE
+#if !defined(CZ_TIMELINE) && !defined(CZ_ABLATE)
 static_assert(sizeof(Params) == 264, "argument block: see the note above");
 #endif
 // Overlapped ("chained") launches: consecutive step kernels of a run go to two streams alternately, so a kernel may start

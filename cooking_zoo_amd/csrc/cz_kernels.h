@@ -270,10 +270,23 @@ __device__ __forceinline__ void load_desc(const Params &P, uint32_t layout, int 
 //       from HBM, queued behind the writes: a one-step launch of 65 536 envs takes 80 us with plain stores and 56 us with
 //       streaming ones (profiles/r03/aux_sweep.txt).
 //   0 = plain: the fused kernel (its launch boundary is amortised over T steps) and batches in between.
+// `codes` (optional, cz_step_device_compact): the same observation as ONE BYTE per feature - the index of the table entry
+// the feature's value is, out[a][f] == lut[codes[a][f]] bit for bit - in rows of codes_pitch(F) bytes (padding: 255, an entry
+// that is 0.0): 1/8 of the bytes for consumers that stay on the device.  Lanes take four adjacent features each, one
+// descriptor b128 load and one 4-byte store per observer and 256 features; no table reads at all.  `out` may be null then.
+__host__ __device__ inline int codes_pitch(int F) { return (F + 15) & ~15; }
+// the descriptor words of this lane's first four features, fetched with the prologue's loads (layout: which row they are of)
+constexpr int CODES_PREFETCH = 2;               // rounds of 256 features (F = 278: both)
+struct CodesPrefetch { uint4_t d[CODES_PREFETCH]; uint32_t layout; };
+__device__ __forceinline__ uint4_t load_desc4(const Params &P, uint32_t layout, uint32_t f) {
+    const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(P.lay_desc), 0, P.L * P.F * 4, 0x00020000);
+    return __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(rd, f * 4u, layout * (uint32_t)P.F * 4u, 0));
+}
 template <int OPL, int CPL, int NA>
 __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, Lds<CPL> &s,
                                         const double *lut, uint32_t (&dsc)[OBS_CHUNK], uint32_t submask, double *__restrict__ out /* [A][F] of this env */,
-                                        bool objs_changed = true, bool cells_changed = true) {
+                                        bool objs_changed = true, bool cells_changed = true, uint8_t *__restrict__ codes = nullptr /* [A][Fp] */,
+                                        const CodesPrefetch *pre = nullptr) {
     uint32_t *img32 = reinterpret_cast<uint32_t *>(s.img);
     const uint32_t dead = (uint32_t)(LUT_ABSENT * 8) * 0x10001u;
     const uint32_t c01 = (uint32_t)((P.W - 1) * 8) | ((uint32_t)((LUT_Y0 + P.H - 1) * 8) << 16);
@@ -327,13 +340,48 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
     // (feature index * 8) is range-checked by the hardware, dword by dword (the scalar offset would be part of that check,
     // so the row's base goes into the resource).  Features past F - whole pairs, or the second half of the last pair when
     // F is odd - are dropped by the memory pipeline and the store sequence needs no lane masks or branches at all.
+    const char *lutb = reinterpret_cast<const char *>(lut);
+    const char *imgb = reinterpret_cast<const char *>(s.img);
+    const char *subb = reinterpret_cast<const char *>(s.sub);
+    if (codes) {
+        const int Fp = codes_pitch(P.F);
+        decltype(__builtin_amdgcn_make_buffer_rsrc(codes, 0, 0, 0)) rc[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) rc[a] = __builtin_amdgcn_make_buffer_rsrc(codes + (size_t)a * (uint32_t)Fp, 0, Fp, 0x00020000);
+        for (int f0 = 0; f0 < P.F; f0 += 256) {
+            const uint32_t f = (uint32_t)f0 + 4u * (uint32_t)cx.lane;                       // this lane's first feature
+            // (the first round's words usually came with the prologue's loads; a reset pass moved the env to another layout)
+            uint4_t d;
+            if (pre && pre->layout == e.layout && f0 < 256 * CODES_PREFETCH) d = f0 == 0 ? pre->d[0] : pre->d[1];
+            else d = load_desc4(P, e.layout, f);
+            const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+            uint32_t b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b[k] = *reinterpret_cast<const uint16_t *>(imgb + (dw[k] & 0xFFFFu));
+            int sb[NA][4];
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sb[a][k] = *reinterpret_cast<const int32_t *>(subb + 64 * a + (dw[k] >> 16));
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // (features past F: descriptor words of the next row, or 0 behind the table's end -> the padding value)
+                    const uint32_t c = (f + (uint32_t)k < (uint32_t)P.F) ? (((uint32_t)((int)b[k] - sb[a][k]) >> 3) & 0xFFu) : (uint32_t)LUT_ABSENT;
+                    w |= c << (8 * k);
+                }
+                // (write-through like the float64 rows of a one-step launch: nothing stays dirty until the end-of-kernel write-back)
+                __builtin_amdgcn_raw_buffer_store_b32(w, rc[a], f, 0, 16);
+            }
+        }
+    }
+    if (!out) { __builtin_amdgcn_wave_barrier(); return; }
     decltype(__builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0)) rs[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) rs[a] = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)a * (uint32_t)P.F, 0, P.F * 8, 0x00020000);
     const uint32_t wt = (uint32_t)P.wt;                                                 // wave-uniform
-    const char *lutb = reinterpret_cast<const char *>(lut);
-    const char *imgb = reinterpret_cast<const char *>(s.img);
-    const char *subb = reinterpret_cast<const char *>(s.sub);
     for (int chunk = 0; chunk * 128 * OBS_PAIRS < P.F; ++chunk) {
         if (chunk > 0) load_desc(P, e.layout, chunk, cx.lane, dsc);
         // branch-free stages so that the LDS reads of all pairs and observers are in flight together
@@ -561,7 +609,9 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
 // ENVS_PER_WG envs per workgroup (one wavefront each, no cross-wave communication).
 // FUSED = 0: one step, actions from memory.  FUSED = 1: P.T steps, on-device action stream, outputs [t][env].  FUSED = 2: P.T
 // steps over the caller's actions [t][env][agent] (cz_rollout_actions; its own instance so that the on-device stream's loop
-// carries none of it: as a run-time branch it cost the random-action rollout 4 %).
+// carries none of it: as a run-time branch it cost the random-action rollout 4 %).  FUSED = 3: one step that also (or only)
+// writes the compact observation (cz_step_device_compact / cz_set_compact_output; its own instance as well: compiled into the
+// ordinary one-step kernel the path cost every launch 0.2 us, register allocation and a longer prologue, even when unused).
 // What the very first loads of a wave need travels as leading scalar kernel arguments: the build preloads them into
 // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, gfx940+), so the record / action / table loads are issued
 // without waiting for an argument fetch; everything else stays in the by-value block `P0`, fetched meanwhile.
@@ -611,7 +661,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     double *retp = reinterpret_cast<double *>(rec + RET_WORD0);
     // ---- an overlapped launch first waits for its env's predecessor (SEQ_* in cz_device.h); ordinary launches skip this
     uint32_t *const seqw = P.state + (size_t)P.N * P.RW + (size_t)env * SEQ_STRIDE_WORDS;
-    constexpr bool FUSED = FUSED_MODE != 0, EXT = FUSED_MODE == 2;
+    constexpr bool FUSED = FUSED_MODE == 1 || FUSED_MODE == 2, EXT = FUSED_MODE == 2, CODES = FUSED_MODE == 3;
     static_assert(!(FUSED && CHAIN), "overlapped launches are one-step launches");
     constexpr bool chained = CHAIN;
     bool abandoned = false;
@@ -678,6 +728,14 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     }
     if (env_raw >= P.N || (CHAIN && abandoned)) return;
     CZ_STAMP(1);
+    // the compact observation's descriptor words (cz_step_device_compact): fetched here, behind the prologue's waits - a branch
+    // on a late argument in front of the prologue's loads costs every launch 0.4 us - and hidden by the dynamics
+    CodesPrefetch cpre;
+    cpre.layout = e.layout;
+    if (CODES) {
+#pragma unroll
+        for (int r = 0; r < CODES_PREFETCH; ++r) cpre.d[r] = load_desc4(P, e.layout, 256u * r + 4u * (uint32_t)lane);
+    }
 
     const int T = FUSED ? P.T : 1;
     // a fused rollout over caller-supplied actions (cz_rollout_actions: [T][N][A] int32): step t's action words are loaded one
@@ -767,9 +825,11 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         CZ_STAMP(5);
         img_objs |= (dt.touched | dt.moved) != 0;
         img_cells |= dt.cells != 0;
-        if (Pt.obs) {
+        if (Pt.obs || CODES) {
             // (env row x row length: a 32 x 32 -> 64-bit product, two scalar multiplies)
-            observe(Pt, e, cx, lds, lut, dsc, submask, Pt.obs + (uint64_t)(uint32_t)row * (uint64_t)(uint32_t)(NA * Pt.F), img_objs, img_cells);
+            uint8_t *const codes = CODES ? Pt.codes + (uint64_t)(uint32_t)row * (uint64_t)(uint32_t)(NA * codes_pitch(Pt.F)) : nullptr;
+            double *const obs_row = Pt.obs ? Pt.obs + (uint64_t)(uint32_t)row * (uint64_t)(uint32_t)(NA * Pt.F) : nullptr;
+            observe(Pt, e, cx, lds, lut, dsc, submask, obs_row, img_objs, img_cells, codes, CODES ? &cpre : nullptr);
             img_objs = false; img_cells = false;
         }
         if (o.finished) {                      // (the state is still that of the finished episode: the reset is the next pass)
@@ -816,7 +876,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
 // waves - and forcing that one to six (80 registers, 3 spilled) changed nothing: 195 against 197 M env-steps/s,
 // profiles/r03/wpe_ab.txt)
 #ifdef CZ_STEP_MIN_WPE
-#define CZ_STEP_ATTR __attribute__((amdgpu_waves_per_eu((FUSED == 0 && OPL <= 2) ? CZ_STEP_MIN_WPE : 1)))
+#define CZ_STEP_ATTR __attribute__((amdgpu_waves_per_eu(((FUSED == 0 || FUSED == 3) && OPL <= 2) ? CZ_STEP_MIN_WPE : 1)))
 #else
 #define CZ_STEP_ATTR
 #endif
@@ -961,6 +1021,9 @@ struct Inst {
             } else {
                 return hipErrorInvalidValue;               // (cz_overlap_limit is 0 for this instance: the host never asks)
             }
+        } else if (P.codes) {
+            if (P.scheme == 3) CZ_LAUNCH_STEP(3, 3);
+            else CZ_LAUNCH_STEP(1, 3);
         } else {
             if (P.scheme == 3) CZ_LAUNCH_STEP(3, 0);
             else CZ_LAUNCH_STEP(1, 0);

@@ -529,6 +529,31 @@ class CookingVecEnv:
                                                             p(d_trunc)))
         self._advance(1)
 
+    def step_device_compact(self, d_actions, d_codes, d_rewards, d_term, d_trunc, d_obs=None):
+        """Device-resident step whose observation is one byte per feature: d_codes uint8 [N, A, codes_pitch] receives the index
+        of every feature's value in `obs_table()` (256 float64; `obs_table()[codes]` is the float64 observation bit for bit).
+        d_obs (optional): the float64 [N, A, F] observation as well."""
+        p = _dev_ptr
+        _native.check(self._h, _native.lib().cz_step_device_compact(self._h, p(d_actions), p(d_codes), p(d_obs), p(d_rewards), p(d_term),
+                                                                    p(d_trunc)))
+        self._advance(1)
+
+    def set_compact_output(self, d_codes=None):
+        """every one-step launch from now on (step_device, step_device_ring, step) also writes the compact observation to d_codes
+        (uint8 [N, A, codes_pitch]); None switches it off.  Pass d_obs=None to those calls for codes only."""
+        _native.check(self._h, _native.lib().cz_set_compact_output(self._h, _dev_ptr(d_codes)))
+
+    @property
+    def codes_pitch(self):
+        """row length of the compact observation in bytes: F rounded up to a multiple of 16 (padding bytes are 255)"""
+        return int(_native.lib().cz_codes_pitch(self._h))
+
+    def obs_table(self):
+        """the 256 float64 values a compact-observation code stands for"""
+        t = np.empty(256, dtype=np.float64)
+        _native.check(self._h, _native.lib().cz_obs_table(self._h, _ptr(t)))
+        return t
+
     def step_device_ring(self, K, d_ring, action_stride, action_period, first_slot, d_obs, d_rewards, d_term, d_trunc):
         """K consecutive device-resident steps in one call (cz_step_device_ring: graph replay or overlapped launches); step k
         reads its actions from ring slot (first_slot + k) % action_period."""

@@ -176,6 +176,21 @@ int cz_last_marks(cz_handle h, uint32_t *marks);
 int cz_step_device(cz_handle h, const int32_t *d_actions, double *d_obs, double *d_rewards,
                    uint8_t *d_terminations, uint8_t *d_truncations);
 
+/* The same step with a COMPACT observation for consumers that stay on the device: every feature of get_feature_vector
+ * (cooking_env.py:352-373) is one of at most 256 values - quotients (x - ax) / W, (y - ay) / H, 0.0, 1.0 - so d_codes
+ * (uint8 [N][A][cz_codes_pitch(h)], pitch = F rounded up to 16, padding bytes 255) receives for every feature the INDEX of its
+ * value in a table of 256 float64 (cz_obs_table: a host copy; cz_obs_table_device: the resident one), i.e.
+ * table[d_codes[e][a][f]] is bit for bit the float64 observation - 1/8 of the bytes, losslessly.  d_obs may be NULL (codes
+ * only) or a float64 [N][A][F] buffer that is written as well. */
+int cz_step_device_compact(cz_handle h, const int32_t *d_actions, uint8_t *d_codes, double *d_obs, double *d_rewards,
+                           uint8_t *d_terminations, uint8_t *d_truncations);
+/* ... or as a setting of the handle: from now on every one-step launch (cz_step_device, _many, _ring, cz_step) writes the compact
+ * observation to d_codes as well - with d_obs = NULL in those calls, instead of the float64 rows; NULL switches it off. */
+int cz_set_compact_output(cz_handle h, uint8_t *d_codes);
+int32_t cz_codes_pitch(cz_handle h);
+int cz_obs_table(cz_handle h, double table[256]);
+const void *cz_obs_table_device(cz_handle h);
+
 /* K consecutive steps, one launch each, issued from C: step k reads its actions at d_actions + (k % action_period) *
  * action_stride (in int32 elements) and overwrites the same output buffers.  Equivalent to K cz_step_device calls. */
 int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_actions, int64_t action_stride, int32_t action_period,
@@ -269,6 +284,10 @@ int cz_probe_output_only(cz_handle h, void *d_dst, size_t bytes, int32_t reps, f
  * step (step + policy).  d_actions (int32 [N][A]) is read and rewritten in place; K <= 1024. */
 int cz_probe_closed_loop(cz_handle h, int32_t K, int32_t reps, int32_t *d_actions, double *d_obs, double *d_rewards,
                          uint8_t *d_terminations, uint8_t *d_truncations, float *us_per_step);
+/* ... the same loop over the compact observation: cz_step_device_compact (codes only), then a policy kernel that reads the same
+ * four features as table indices - it takes the same actions as cz_probe_closed_loop's. */
+int cz_probe_closed_loop_compact(cz_handle h, int32_t K, int32_t reps, int32_t *d_actions, uint8_t *d_codes, double *d_rewards,
+                                 uint8_t *d_terminations, uint8_t *d_truncations, float *us_per_step);
 /* test aid: `workgroups` workgroups of a foreign kernel (512 threads and 34 KB of LDS each, like the step kernel's) hold
  * their slots for `microseconds` on a stream of their own; returns at once.  Stands in for a caller's own long-running
  * kernels next to an overlapped run. */

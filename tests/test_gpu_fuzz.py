@@ -42,7 +42,8 @@ def draw_case(i):
     # ---- the device paths of rounds 3 / 4 (drawn from a second stream, so that the cases above stay what they were)
     rng2 = np.random.default_rng(77000 + i)
     extra = {"wide": False, "rotate": False}
-    if rng2.random() < 0.4:                           # despawn / respawn inside the kernels (cz_set_spawn)
+    spawn_ok = not (level == "edge_empty" and agents > 2)     # (that level file places two agents only: no spawn area for a third)
+    if rng2.random() < 0.4 and spawn_ok:              # despawn / respawn inside the kernels (cz_set_spawn)
         kw.update(agent_despawn_rate=float(rng2.choice([0.02, 0.1, 0.3])), agent_respawn_rate=float(rng2.choice([0.05, 0.25, 0.6])),
                   grace_period=int(rng2.integers(0, 6)), spawn_seed=int(rng2.integers(1 << 40)))
     if rng2.random() < 0.2:                           # a user recipe book with a 10-node graph: wide recipe tables
