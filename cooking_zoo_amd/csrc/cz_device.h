@@ -222,24 +222,23 @@ struct Mask {
             if (w[k]) r = 64 * k + 63 - __clzll((long long)w[k]);
         return r;
     }
+    // (word / set / clear by arithmetic on every word, not "if (j == k) touch w[j]": the optimiser turns such a chain into a
+    // dynamically indexed access, which sends the whole set - scalar registers - to a scratch-memory array)
     __device__ __forceinline__ uint64_t word(int k) const {
         if (N == 1) return w[0];
         uint64_t v = 0;
 #pragma unroll
-        for (int j = 0; j < N; ++j)
-            if (j == k) v = w[j];
+        for (int j = 0; j < N; ++j) v |= w[j] & (0ull - (uint64_t)(j == k));
         return v;
     }
     __device__ __forceinline__ bool test(int s) const { return s >= 0 && ((word(s >> 6) >> (s & 63)) & 1); }
     __device__ __forceinline__ void set(int s) {
 #pragma unroll
-        for (int j = 0; j < N; ++j)
-            if (N == 1 || j == (s >> 6)) w[j] |= 1ull << (s & 63);
+        for (int j = 0; j < N; ++j) w[j] |= (uint64_t)(N == 1 || j == (s >> 6)) << (s & 63);
     }
     __device__ __forceinline__ void clear(int s) {
 #pragma unroll
-        for (int j = 0; j < N; ++j)
-            if (N == 1 || j == (s >> 6)) w[j] &= ~(1ull << (s & 63));
+        for (int j = 0; j < N; ++j) w[j] &= ~((uint64_t)(N == 1 || j == (s >> 6)) << (s & 63));
     }
     __device__ __forceinline__ Mask operator&(const Mask &o) const {
         Mask r;
@@ -557,11 +556,22 @@ struct Ops {
     // in agent order (action_scheme3.py:15-16) and pulls one agent out of the vectors with v_readlane.
     // bit `c` of a cell-set mask, per lane
     static __device__ __forceinline__ bool cell_bit(const CM &m, uint32_t c) {
-        uint64_t w = m.w[0];
+        if constexpr (CPL == 1) {
+            return ((m.w[0] >> (c & 63u)) & 1ull) != 0ull;
+        } else {
+            // Word by word, each as two 32-bit scalars: "pick the word by c >> 6, then shift" is a select chain over the set's
+            // words, which the optimiser turns into a dynamically indexed load - and the set, eight scalar registers, into a
+            // scratch-memory array: a store and a dependent load from memory in the middle of every step, and 6 KB of scratch
+            // written per wave (the "WRITE_SIZE = 1.17 x algorithmic" of config 5 up to round 3; profiles/r04/README.md).
+            uint32_t hit = 0u;
 #pragma unroll
-        for (int k = 1; k < CPL; ++k)
-            if ((c >> 6) == (uint32_t)k) w = m.w[k];
-        return ((w >> (c & 63u)) & 1ull) != 0ull;
+            for (int k = 0; k < CPL; ++k) {
+                const uint32_t lo = (uint32_t)m.w[k], hi = (uint32_t)(m.w[k] >> 32);
+                const uint32_t half = (c & 32u) ? hi : lo;
+                hit |= ((c >> 6) == (uint32_t)k) ? (half >> (c & 31u)) : 0u;
+            }
+            return (hit & 1u) != 0u;
+        }
     }
     // the value of lane `lane ^ 1` / of the next lanes of the quad (agents live in lanes 0..3: DPP, no LDS, no SGPR trip)
     template <int CTRL>
