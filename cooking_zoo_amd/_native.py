@@ -63,6 +63,7 @@ SYMBOLS = [
     ("cz_step_device", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     ("cz_step_device_compact", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("cz_set_compact_output", C.c_int, [_VP, _VP]),
+    ("cz_step_compact", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     ("cz_codes_pitch", _I32, [_VP]),
     ("cz_obs_table", C.c_int, [_VP, _VP]),
     ("cz_obs_table_device", _VP, [_VP]),

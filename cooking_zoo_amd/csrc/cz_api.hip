@@ -193,6 +193,7 @@ struct cz_handle_s {
     double *d_lut = nullptr;
     double obs_table[LUT_SIZE];        // host copy of the quotient table (cz_obs_table: what the compact observation's codes index)
     int32_t *d_reset_words = nullptr;  // [3][N]: layout ids, recipe words, pool words of a cz_reset call
+    void *d_codes_stage = nullptr;     // cz_step_compact with pageable host memory: device staging of the codes
     void *d_dump = nullptr;            // [N][4] doubles: where a one-step launch writes an output array the caller passed as NULL
     // staging for the host-pointer API
     int32_t *d_actions = nullptr;
@@ -495,7 +496,7 @@ extern "C" int cz_destroy(cz_handle h) {
         destroy_t f = (destroy_t)dlsym(h->rccl, "ncclCommDestroy");
         if (f) f(h->comm);
     }
-    void *ptrs[] = {h->d_spawn_tables, h->d_reset_words, h->d_dump, h->d_lut, h->d_state, h->d_lay_block, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out, h->d_stats_part,
+    void *ptrs[] = {h->d_codes_stage, h->d_spawn_tables, h->d_reset_words, h->d_dump, h->d_lut, h->d_state, h->d_lay_block, h->d_lay_desc, h->d_recipes, h->d_stat_u, h->d_stat_f, h->d_stats_out, h->d_stats_part,
                     h->d_actions, h->d_obs, h->d_small, h->d_gather};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1438,6 +1439,28 @@ extern "C" int cz_step(cz_handle h, const int32_t *actions, double *obs, double 
     memcpy(term, h->h_small + s_term, NA);
     memcpy(trunc, h->h_small + s_trunc, NA);
     h->last_marks.assign((const uint32_t *)(h->h_small + s_marks), (const uint32_t *)(h->h_small + s_marks) + 2 * (size_t)h->P.N);
+    return 0;
+}
+
+// The host-pointer step with the COMPACT observation instead of the float64 rows: codes uint8 [N][A][cz_codes_pitch] (see
+// cz_step_device_compact) - 1/8 of the bytes that have to cross PCIe, which is what a host-array step of thousands of envs
+// spends its time on.  Buffers from cz_host_alloc are written by the kernel directly; others through a device staging block.
+extern "C" int cz_step_compact(cz_handle h, const int32_t *actions, uint8_t *codes, double *rewards, uint8_t *term, uint8_t *trunc) {
+    if (ready(h)) return 1;
+    if (!codes) return fail(h, "cz_step_compact: null codes buffer");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const size_t bytes = (size_t)h->P.N * h->P.A * (size_t)codes_pitch(h->P.F);
+    uint8_t *const saved = h->P.codes;
+    void *direct = mapped_device_pointer(codes);
+    if (!direct && !h->d_codes_stage) HIPCHK(h, hipMalloc(&h->d_codes_stage, bytes));
+    h->P.codes = direct ? (uint8_t *)direct : (uint8_t *)h->d_codes_stage;
+    const int rc = cz_step(h, actions, nullptr, rewards, term, trunc);
+    h->P.codes = saved;
+    if (rc) return rc;
+    if (!direct) {
+        HIPCHK(h, hipMemcpyAsync(codes, h->d_codes_stage, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     return 0;
 }
 

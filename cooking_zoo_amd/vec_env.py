@@ -476,6 +476,24 @@ class CookingVecEnv:
         self._advance(1)
         return obs, rew, term, trunc
 
+    def step_compact(self, actions):
+        """`step` with the observation as one byte per feature: -> (codes uint8 [N, A, codes_pitch], rewards, terminations,
+        truncations); `obs_table()[codes[..., :F]]` is the float64 observation bit for bit.  An eighth of the bytes over PCIe."""
+        N, A = self.num_envs, self.num_agents
+        acts = self._host_array("act", (N, A), np.int32)
+        acts[...] = np.asarray(actions).reshape(N, A)
+        if acts.size and int(acts.max()) >= self.n_actions:
+            raise ValueError(f"actions must be in [0, {self.n_actions}) for {self.action_scheme} (negative = despawned agent)")
+        codes = self._host_array("codes", (N, A, self.codes_pitch), np.uint8)
+        rew = self._host_array("rew", (N, A), np.float64)
+        term = self._host_array("term", (N, A), np.uint8)
+        trunc = self._host_array("trunc", (N, A), np.uint8)
+        _native.check(self._h, _native.lib().cz_step_compact(self._h, _ptr(acts), _ptr(codes), _ptr(rew), _ptr(term), _ptr(trunc)))
+        if self.spawn is not None:
+            self.spawn.refresh()
+        self._advance(1)
+        return codes, rew, term, trunc
+
     def last_marks(self):
         """Recipe-node marks after the most recent host-array `step`: uint64 [N], bit 8r + j = node j of the env's r-th
         recipe (compact tables) or bit 16r + j (wide tables, `recipe_nodes == 16`)."""

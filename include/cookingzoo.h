@@ -187,6 +187,8 @@ int cz_step_device_compact(cz_handle h, const int32_t *d_actions, uint8_t *d_cod
 /* ... or as a setting of the handle: from now on every one-step launch (cz_step_device, _many, _ring, cz_step) writes the compact
  * observation to d_codes as well - with d_obs = NULL in those calls, instead of the float64 rows; NULL switches it off. */
 int cz_set_compact_output(cz_handle h, uint8_t *d_codes);
+/* host-pointer form (synchronous, like cz_step) that returns the codes instead of the float64 rows: 1/8 of the bytes over PCIe */
+int cz_step_compact(cz_handle h, const int32_t *actions, uint8_t *codes, double *rewards, uint8_t *terminations, uint8_t *truncations);
 int32_t cz_codes_pitch(cz_handle h);
 int cz_obs_table(cz_handle h, double table[256]);
 const void *cz_obs_table_device(cz_handle h);

@@ -120,3 +120,28 @@ def test_compact_step_argument_errors():
     assert L.cz_step_device_compact(env._h, d.ptr, None, None, None, None, None) != 0
     assert b"codes" in L.cz_last_error(env._h)
     env.close()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_array_step_with_codes(pinned):
+    """CookingVecEnv.step_compact (cz_step_compact): pageable arrays through the staging block, pinned ones written by the kernel"""
+    from oracle_binding import VecOracle
+    n, A = 300, 2
+    env = make(n, "coop_test", "example", A, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3", pinned_outputs=pinned)
+    orc = VecOracle.from_vec_env(env)
+    env.reset(return_obs=False)
+    orc.reset()
+    table = env.obs_table()
+    rng = np.random.default_rng(3)
+    for t in range(40):
+        acts = rng.integers(0, 5, size=(n, A), dtype=np.int32)
+        codes, rg, tg, ug = env.step_compact(acts)
+        oo, ro, to, uo = orc.step(acts)
+        assert codes.shape == (n, A, env.codes_pitch)
+        assert np.array_equal(bits(table[codes[:, :, :env.F]]), bits(oo)), t
+        assert np.array_equal(bits(rg), bits(ro)) and np.array_equal(tg, to) and np.array_equal(ug, uo)
+    # the ordinary step afterwards is untouched by the compact one
+    og, rg, tg, ug = env.step(acts)
+    oo, ro, to, uo = orc.step(acts)
+    assert np.array_equal(bits(og), bits(oo))
+    env.close()

@@ -118,9 +118,14 @@ def run_case(i, kw, seed, extra):
     # ... and on from there with one launch per step and actions from the host (the other kernel variant)
     rng = np.random.default_rng(seed)
     n_act = 5 if kw["action_scheme"] == "scheme3" else 8
+    table = env.obs_table()
     for t in range(25):
         acts = rng.integers(0, n_act, size=(n, A), dtype=np.int32)
-        o, r, te, tr = env.step(acts)
+        if t % 4 == 3:                               # the compact observation (its own kernel instance): decoded, it is the same
+            codes, r, te, tr = env.step_compact(acts)
+            o = table[codes[:, :, :env.F]]
+        else:
+            o, r, te, tr = env.step(acts)
         oo, ro, to, uo = orc.step(acts)
         assert np.array_equal(bits(o), bits(oo)) and np.array_equal(bits(r), bits(ro)), (ctx, t)
         assert np.array_equal(te, to) and np.array_equal(tr, uo), (ctx, t)

@@ -23,6 +23,14 @@ for pinned in (False, True):
     dt = (time.perf_counter() - t0) / K
     bytes_back = obs.nbytes + rew.nbytes + term.nbytes + trunc.nbytes
     print(f"{N} envs, pinned_outputs={pinned}: {dt * 1e6:7.1f} us per host-array step  ({N / dt / 1e6:.1f} M env-steps/s, {bytes_back / dt / 1e9:.1f} GB/s of outputs)")
+    for i in range(10):
+        env.step_compact(acts[i])
+    t0 = time.perf_counter()
+    for i in range(K):
+        codes, rew, term, trunc = env.step_compact(acts[i % 64])
+    dt = (time.perf_counter() - t0) / K
+    print(f"{N} envs, pinned_outputs={pinned}, COMPACT observation (uint8 codes, {codes.nbytes / 1e6:.1f} MB instead of {obs.nbytes / 1e6:.1f} MB): "
+          f"{dt * 1e6:7.1f} us per host-array step  ({N / dt / 1e6:.1f} M env-steps/s)")
     t0 = time.perf_counter()
     for i in range(K):
         env.step(acts[i % 64], return_obs=False)
