@@ -171,6 +171,31 @@ def leg_fused(env, K):
             b.free()
 
 
+def leg_fused_compact(env, K):
+    """T = 32 fused steps per launch with a COMPACT trajectory (cz_rollout_compact: uint8 codes [T][N][A][pitch], decodable bit for
+    bit with the 256-entry table): what a learner that embeds the codes reads back, at an eighth of the trajectory's bytes"""
+    N, A, T = env.num_envs, env.num_agents, 32
+    d_codes = env.alloc((T, N, A, env.codes_pitch), np.uint8)
+    try:
+        reps = max(2, min(K, 2000) // T)
+        env.rollout_compact(T, 1, 0, d_codes)
+        env.sync()
+        f0 = env.stats()["env_steps"]
+        t0 = time.perf_counter()
+        for r in range(reps):
+            env.rollout_compact(T, 1, (r + 1) * T, d_codes)
+        env.sync()
+        dt = time.perf_counter() - t0
+        b_alg = algorithmic_bytes_per_env_step(env) - A * 8 * env.F + A * env.F
+        out = {"env_steps_per_s_per_gpu": (env.stats()["env_steps"] - f0) / dt, "steps_per_launch": T, "ms_per_step": dt * 1e3 / (reps * T),
+               "api": "cz_rollout_compact: uint8 code trajectory [T][N][A][%d] in HBM (no float64 rows)" % env.codes_pitch}
+        out["roofline"] = roofline_block(b_alg, N, out["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,4> (32 steps per launch, codes)",
+                                         "wall clock around the cz_rollout_compact launches; algorithmic bytes with 1 byte per feature")
+        return out
+    finally:
+        d_codes.free()
+
+
 def leg_closed_loop(env, d_obs, d_rew, d_term, d_trunc):
     """What a reinforcement-learning loop gets: cz_step_device, then a kernel of the caller that turns the observation into the
     next actions, then the next step - every step waits for a policy that waits for the step before it.  (The policy here is
@@ -775,6 +800,7 @@ def worker_body(args, rdzv, overlap, note):
             # what users get beside the open-loop headline; each leg a fraction of a second of GPU time.
             # An extra leg must never be able to lose the headline measured above: whatever it raises is recorded under its key.
             line["fused_actions"] = guarded(leg_fused_actions, env, K)
+            line["fused_compact"] = guarded(leg_fused_compact, env, K)
             line["closed_loop"] = guarded(leg_closed_loop, env, d_obs, d_rew, d_term, d_trunc)
             line["closed_loop_compact"] = guarded(leg_closed_loop_compact, env, d_rew, d_term, d_trunc)
             line["cooking_policy"] = guarded(leg_cooking_policy, local_rank)

@@ -81,6 +81,7 @@ SYMBOLS = [
     ("cz_probe_occupy", C.c_int, [_VP, _I32, _I32]),
     ("cz_probe_closed_loop", C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, C.POINTER(C.c_float)]),
     ("cz_rollout", C.c_int, [_VP, _I32, _U64, _U32, _VP, _VP, _VP, _VP]),
+    ("cz_rollout_compact", C.c_int, [_VP, _I32, _U64, _U32, _VP, _VP, _VP, _VP, _VP]),
     ("cz_rollout_actions", C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP]),
     ("cz_action", _U32, [_U64, _I64, _I32, _U32, _U32]),
     ("cz_next_layout", _U32, [_I64, _U32, _U32, _U32]),

@@ -1321,7 +1321,24 @@ extern "C" int cz_rollout(cz_handle h, int32_t T, uint64_t seed, uint32_t step0,
     if (set_device(h)) return 1;
     if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
     Params P = h->P;
-    P.actions = nullptr; P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc;
+    P.actions = nullptr; P.obs = d_obs; P.codes = nullptr; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc;
+    P.T = T; P.seed = seed; P.step0 = step0;
+    return launch_step(h, P, nullptr, true);
+}
+
+// ... with a COMPACT trajectory: d_codes uint8 [T][N][A][cz_codes_pitch] (one byte per feature, see cz_step_device_compact) instead
+// of - or, with d_obs, next to - the float64 one: an eighth of the bytes a learner has to read back
+extern "C" int cz_rollout_compact(cz_handle h, int32_t T, uint64_t seed, uint32_t step0, uint8_t *d_codes, double *d_obs, double *d_rewards,
+                                  uint8_t *d_term, uint8_t *d_trunc) {
+    if (ready(h)) return 1;
+    if (T < 1 || !d_codes) return fail(h, "cz_rollout_compact: T must be >= 1 and the codes pointer non-null");
+    if ((uint64_t)T * (uint64_t)h->P.N * (uint64_t)h->P.A * 8ull > 0xFFFFFFFFull)
+        return fail(h, "cz_rollout_compact: T * num_envs * num_agents * 8 must stay below 4 GiB (T <= %llu here): split the rollout",
+                    (unsigned long long)(0xFFFFFFFFull / ((uint64_t)h->P.N * h->P.A * 8ull)));
+    if (set_device(h)) return 1;
+    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;
+    Params P = h->P;
+    P.actions = nullptr; P.obs = d_obs; P.codes = d_codes; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc;
     P.T = T; P.seed = seed; P.step0 = step0;
     return launch_step(h, P, nullptr, true);
 }
@@ -1340,7 +1357,7 @@ extern "C" int cz_rollout_actions(cz_handle h, int32_t T, const int32_t *d_actio
     if (set_device(h)) return 1;
     if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
     Params P = h->P;
-    P.actions = d_actions; P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc;
+    P.actions = d_actions; P.obs = d_obs; P.codes = nullptr; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc;
     P.T = T; P.seed = 0; P.step0 = 0;
     return launch_step(h, P, nullptr, true);
 }

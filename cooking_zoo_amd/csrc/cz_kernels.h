@@ -286,7 +286,7 @@ template <int OPL, int CPL, int NA>
 __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, Lds<CPL> &s,
                                         const double *lut, uint32_t (&dsc)[OBS_CHUNK], uint32_t submask, double *__restrict__ out /* [A][F] of this env */,
                                         bool objs_changed = true, bool cells_changed = true, uint8_t *__restrict__ codes = nullptr /* [A][Fp] */,
-                                        const CodesPrefetch *pre = nullptr) {
+                                        CodesPrefetch *pre = nullptr) {
     uint32_t *img32 = reinterpret_cast<uint32_t *>(s.img);
     const uint32_t dead = (uint32_t)(LUT_ABSENT * 8) * 0x10001u;
     const uint32_t c01 = (uint32_t)((P.W - 1) * 8) | ((uint32_t)((LUT_Y0 + P.H - 1) * 8) << 16);
@@ -348,11 +348,17 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
         decltype(__builtin_amdgcn_make_buffer_rsrc(codes, 0, 0, 0)) rc[NA];
 #pragma unroll
         for (int a = 0; a < NA; ++a) rc[a] = __builtin_amdgcn_make_buffer_rsrc(codes + (size_t)a * (uint32_t)Fp, 0, Fp, 0x00020000);
+        // (the first rounds' descriptor words are kept in registers - fetched behind the prologue, kept across the steps of a fused
+        // rollout - and fetched again when a reset pass has moved the env to another layout)
+        if (pre && pre->layout != e.layout) {
+#pragma unroll
+            for (int r = 0; r < CODES_PREFETCH; ++r) pre->d[r] = load_desc4(P, e.layout, 256u * r + 4u * (uint32_t)cx.lane);
+            pre->layout = e.layout;
+        }
         for (int f0 = 0; f0 < P.F; f0 += 256) {
             const uint32_t f = (uint32_t)f0 + 4u * (uint32_t)cx.lane;                       // this lane's first feature
-            // (the first round's words usually came with the prologue's loads; a reset pass moved the env to another layout)
             uint4_t d;
-            if (pre && pre->layout == e.layout && f0 < 256 * CODES_PREFETCH) d = f0 == 0 ? pre->d[0] : pre->d[1];
+            if (pre && f0 < 256 * CODES_PREFETCH) d = f0 == 0 ? pre->d[0] : pre->d[1];
             else d = load_desc4(P, e.layout, f);
             const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
             uint32_t b[4];
@@ -612,6 +618,7 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
 // carries none of it: as a run-time branch it cost the random-action rollout 4 %).  FUSED = 3: one step that also (or only)
 // writes the compact observation (cz_step_device_compact / cz_set_compact_output; its own instance as well: compiled into the
 // ordinary one-step kernel the path cost every launch 0.2 us, register allocation and a longer prologue, even when unused).
+// FUSED = 4: P.T steps over the on-device action stream with a compact trajectory [t][env][agent][pitch] (cz_rollout_compact).
 // What the very first loads of a wave need travels as leading scalar kernel arguments: the build preloads them into
 // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, gfx940+), so the record / action / table loads are issued
 // without waiting for an argument fetch; everything else stays in the by-value block `P0`, fetched meanwhile.
@@ -661,7 +668,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     double *retp = reinterpret_cast<double *>(rec + RET_WORD0);
     // ---- an overlapped launch first waits for its env's predecessor (SEQ_* in cz_device.h); ordinary launches skip this
     uint32_t *const seqw = P.state + (size_t)P.N * P.RW + (size_t)env * SEQ_STRIDE_WORDS;
-    constexpr bool FUSED = FUSED_MODE == 1 || FUSED_MODE == 2, EXT = FUSED_MODE == 2, CODES = FUSED_MODE == 3;
+    constexpr bool FUSED = FUSED_MODE == 1 || FUSED_MODE == 2 || FUSED_MODE == 4, EXT = FUSED_MODE == 2, CODES = FUSED_MODE == 3 || FUSED_MODE == 4;
     static_assert(!(FUSED && CHAIN), "overlapped launches are one-step launches");
     constexpr bool chained = CHAIN;
     bool abandoned = false;
@@ -732,7 +739,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     // on a late argument in front of the prologue's loads costs every launch 0.4 us - and hidden by the dynamics
     CodesPrefetch cpre;
     cpre.layout = e.layout;
-    if (CODES) {
+    if (CODES && !FUSED) {
 #pragma unroll
         for (int r = 0; r < CODES_PREFETCH; ++r) cpre.d[r] = load_desc4(P, e.layout, 256u * r + 4u * (uint32_t)lane);
     }
@@ -760,6 +767,13 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
             Pt.dyn0_off = e_dyn0; Pt.dyn1_off = e_dyn1;
         } else {
             Pt = P;
+        }
+        if (CODES && FUSED) {
+            // (a fused rollout fetches the code descriptors again at the top of every step - hidden by the step's dynamics - instead
+            // of holding eight more registers across the loop: with them the kernel no longer fits four waves per SIMD)
+            cpre.layout = e.layout;
+#pragma unroll
+            for (int r = 0; r < CODES_PREFETCH; ++r) cpre.d[r] = load_desc4(Pt, e.layout, 256u * r + 4u * (uint32_t)lane);
         }
         uint32_t acts;                                             // lane a = action of agent a
         if (!FUSED) acts = (uint32_t)av;
@@ -1009,6 +1023,9 @@ struct Inst {
         if (fused && P.actions) {
             if (P.scheme == 3) CZ_LAUNCH_STEP(3, 2);
             else CZ_LAUNCH_STEP(1, 2);
+        } else if (fused && P.codes) {
+            if (P.scheme == 3) CZ_LAUNCH_STEP(3, 4);
+            else CZ_LAUNCH_STEP(1, 4);
         } else if (fused) {
             if (P.scheme == 3) CZ_LAUNCH_STEP(3, 1);
             else CZ_LAUNCH_STEP(1, 1);

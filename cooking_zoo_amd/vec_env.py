@@ -586,6 +586,13 @@ class CookingVecEnv:
                                                         p(d_term), p(d_trunc)))
         self._advance(T)
 
+    def rollout_compact(self, T, seed, step0, d_codes, d_obs=None, d_rewards=None, d_term=None, d_trunc=None):
+        """`rollout` with a compact trajectory: d_codes uint8 [T, N, A, codes_pitch] (and, optionally, the float64 one)"""
+        p = _dev_ptr
+        _native.check(self._h, _native.lib().cz_rollout_compact(self._h, int(T), int(seed), int(step0), p(d_codes), p(d_obs), p(d_rewards),
+                                                                p(d_term), p(d_trunc)))
+        self._advance(T)
+
     def rollout_actions(self, d_actions, T, d_obs=None, d_rewards=None, d_term=None, d_trunc=None):
         """T fused steps over the caller's actions (device int32 [T, N, A]); every step's outputs go to the trajectory
         buffers ([T, N, A, F] / [T, N, A]).  Same results as T `step_device` calls over those rows."""

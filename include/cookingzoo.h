@@ -249,6 +249,11 @@ int cz_chain_counts(cz_handle h, int64_t *chained_kernels, int32_t reset);
 int cz_rollout(cz_handle h, int32_t T, uint64_t seed, uint32_t step0, double *d_obs, double *d_rewards,
                uint8_t *d_terminations, uint8_t *d_truncations);
 
+/* ... with the trajectory as compact observations: d_codes uint8 [T][N][A][cz_codes_pitch(h)] (cz_step_device_compact explains the
+ * codes); d_obs (float64 [T][N][A][F]) may be NULL - codes only - or is written as well. */
+int cz_rollout_compact(cz_handle h, int32_t T, uint64_t seed, uint32_t step0, uint8_t *d_codes, double *d_obs, double *d_rewards,
+                       uint8_t *d_terminations, uint8_t *d_truncations);
+
 /* The same fused launch over actions of the caller (replay, open-loop search): d_actions int32 [T][N][A], step t reads row t
  * (values as for cz_step_device: action & 7, negative = the agent does not act).  Same results as T cz_step_device launches
  * over those rows, with every step's outputs in the trajectory buffers. */

@@ -145,3 +145,34 @@ def test_host_array_step_with_codes(pinned):
     oo, ro, to, uo = orc.step(acts)
     assert np.array_equal(bits(og), bits(oo))
     env.close()
+
+
+@pytest.mark.parametrize("scheme,level,agents,recipes,meta", [CASES[0], CASES[1], CASES[4], CASES[6], CASES[11]])
+def test_fused_rollout_with_a_compact_trajectory(scheme, level, agents, recipes, meta):
+    """cz_rollout_compact: T fused steps, codes of every step (and, second launch, the float64 trajectory beside them)"""
+    from oracle_binding import VecOracle
+    n, T, seed = 40, 45, 321
+    env = make(n, level, meta, agents, recipes, scheme, max_steps=20)
+    orc = VecOracle.from_vec_env(env)
+    env.reset(return_obs=False)
+    orc.reset()
+    A, F, Fp = agents, env.F, env.codes_pitch
+    table = env.obs_table()
+    d_codes, d_obs = env.alloc((T, n, A, Fp), np.uint8), env.alloc((T, n, A, F), np.float64)
+    d_rew, d_u = env.alloc((T, n, A), np.float64), env.alloc((T, n, A), np.uint8)
+    lib = orc.oracle.lib
+    for launch, with_obs in enumerate((False, True)):
+        env.rollout_compact(T, seed, launch * T, d_codes, d_obs if with_obs else None, d_rew, None, d_u)
+        env.sync()
+        codes, rew, trunc = d_codes.to_host(), d_rew.to_host(), d_u.to_host()
+        obs = d_obs.to_host() if with_obs else None
+        for t in range(T):
+            acts = np.array([[lib.czo_action(seed, e, a, launch * T + t, env.n_actions) for a in range(A)] for e in range(n)], dtype=np.int32)
+            oo, ro, to, uo = orc.step(acts)
+            assert np.array_equal(bits(table[codes[t][:, :, :F]]), bits(oo)), (launch, t)
+            assert (codes[t][:, :, F:] == 255).all()
+            if with_obs:
+                assert np.array_equal(bits(obs[t]), bits(oo)), (launch, t)
+            assert np.array_equal(bits(rew[t]), bits(ro)) and np.array_equal(trunc[t], uo)
+        assert np.array_equal(strip(env.get_state()), orc.records)
+    env.close()
