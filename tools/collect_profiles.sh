@@ -35,7 +35,7 @@ def pmc(d, pat):
             if pat in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k:(sum(v)/len(v), len(v)) for k,v in agg.items()}
 out={}
-for pat,key in (("k_step<1, 1, 2, 3, false>", "step"), ("k_step<1, 1, 2, 3, true>", "fused")):
+for pat,key in (("k_step<1, 1, 2, 3, 0>", "step"), ("k_step<1, 1, 2, 3, 1>", "fused")):
     f=pmc(O+"/fetch", pat); w=pmc(O+"/write", pat); i=pmc(O+"/insts", pat)
     out[key]={"FETCH_SIZE_KB_per_launch": f.get("FETCH_SIZE",(None,0))[0], "WRITE_SIZE_KB_per_launch": w.get("WRITE_SIZE",(None,0))[0],
               "insts": {k:v[0] for k,v in i.items()}, "dispatches": {"fetch": f.get("FETCH_SIZE",(0,0))[1], "write": w.get("WRITE_SIZE",(0,0))[1]}}

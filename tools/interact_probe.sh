@@ -7,7 +7,7 @@ import csv, glob, collections
 rows = collections.defaultdict(dict)
 for f in glob.glob("gpurun_out/ip/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "3, false>" in r["Kernel_Name"]:
+        if "3, 0>" in r["Kernel_Name"]:
             rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
 ids = sorted(rows)
 n = len(ids) // 3
