@@ -761,7 +761,7 @@ def worker_body(args, rdzv, overlap, note):
                        "envs_per_gpu": N, "parallelism": f"env-sharded x{world}, one wavefront per env, one process per GPU, no torch",
                        "api": api},
             # The dominant kernel's roofline is quoted from the launch-boundary-ordered kernel, cz::k_step<1,1,2,3,0>: its HIP-event
-            # launch duration agrees with rocprofv3's per-kernel average for that kernel (profiles/r03/kernel_stats_ordered.csv).  When
+            # launch duration agrees with rocprofv3's per-kernel average for that kernel (profiles/r04/kernel_stats_ordered.csv).  When
             # the timed regions ran as overlapped launches, the launch-to-launch interval of those is given next to it, with
             # the device-clock timeline that shows it (a per-kernel trace cannot: two of those kernels are resident at a time).
             "roofline": {"bound": "hbm", "achieved": b_alg * N / (kernel_us[1] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -770,14 +770,14 @@ def worker_body(args, rdzv, overlap, note):
                          "kernel_us": kernel_us[1],
                          "kernel_us_from": (f"HIP events on the kernels' stream around {max(R * K, 4000)} launches issued back to back (graph replay, "
                                             f"ordered by launch boundaries), divided by the number of launches; rocprofv3 --kernel-trace of the same "
-                                            f"launches: profiles/r03/kernel_stats_ordered.csv"),
-                         "traffic_from": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately) of the same kernel: profiles/r03/traffic.json",
+                                            f"launches: profiles/r04/kernel_stats_ordered.csv"),
+                         "traffic_from": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately) of the same kernel: profiles/r04/traffic.json",
                          "alg_bytes_per_env_step": b_alg, "units_per_launch": N,
                          "overlapped_launch_interval_us": kernel_med if overlapped else None,
                          "overlapped_frac": (achieved / HBM_PEAK_GBS) if overlapped else None,
                          "overlapped_from": ("HIP events around the same number of OVERLAPPED launches (two streams alternately, per-env sequence words: "
                                              "cz::k_step_chain<1,1,2,3>); the device-clock timeline of such a run - start-to-start interval of "
-                                             "consecutive launches - is profiles/r03/timeline_overlapped.json") if overlapped else None,
+                                             "consecutive launches - is profiles/r04/timeline_overlapped.json") if overlapped else None,
                          # measured on this box, same run: a kernel of the same grid shape that ONLY writes the observation
                          # bytes (write-through 16-byte stores); write-only traffic does not reach the 8 TB/s read+write peak
                          "output_only_launch_us": out_only_us,

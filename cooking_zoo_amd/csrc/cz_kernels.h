@@ -53,9 +53,6 @@ constexpr int ENVS_PER_WG = CZ_ENVS_PER_WG;   // one wavefront per env, this man
 // the huge instance keeps 13.6 KB of LDS per env: four of them (the minimum that still stages the 256-entry table with one
 // entry per thread) fit the 64 KB a workgroup may declare
 template <int CPL> constexpr int envs_per_wg() { return CPL > 4 ? 4 : ENVS_PER_WG; }
-#ifndef CZ_OBS_MASK
-#define CZ_OBS_MASK 0
-#endif
 constexpr int OBS_PAIRS = 3;       // feature pairs per lane and chunk: 3 x 128 = 384 features per chunk
 constexpr int OBS_CHUNK = 2 * OBS_PAIRS;   // descriptor words held per lane
 
@@ -398,39 +395,6 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
         uint32_t b[OBS_CHUNK];
         int sb[NA][OBS_CHUNK];
         double2_t v[NA][OBS_PAIRS];
-#if CZ_OBS_MASK
-        // Lanes whose pair lies past the row (most lanes of the last pair: F = 278 fills 11 of its 64 lanes) are switched off for
-        // the LDS reads: the LDS pipe serves a wave's instruction in groups of lanes and skips groups that are entirely off.
-        bool on[OBS_PAIRS];
-#pragma unroll
-        for (int i = 0; i < OBS_PAIRS; ++i) on[i] = (uint32_t)(chunk * OBS_PAIRS * 128 + i * 128 + 2 * cx.lane) < (uint32_t)P.F;
-#pragma unroll
-        for (int i = 0; i < OBS_PAIRS; ++i) {
-            b[2 * i] = b[2 * i + 1] = 0u;
-#pragma unroll
-            for (int a = 0; a < NA; ++a) sb[a][2 * i] = sb[a][2 * i + 1] = 0;
-            if (on[i]) {
-#pragma unroll
-                for (int j = 2 * i; j < 2 * i + 2; ++j) {
-                    b[j] = *reinterpret_cast<const uint16_t *>(imgb + (dsc[j] & 0xFFFFu));
-#pragma unroll
-                    for (int a = 0; a < NA; ++a) sb[a][j] = *reinterpret_cast<const int32_t *>(subb + 64 * a + (dsc[j] >> 16));
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < OBS_PAIRS; ++i) {
-#pragma unroll
-            for (int a = 0; a < NA; ++a) v[a][i] = double2_t{0.0, 0.0};
-            if (on[i]) {
-#pragma unroll
-                for (int a = 0; a < NA; ++a) {
-                    v[a][i].x = *reinterpret_cast<const double *>(lutb + ((int)b[2 * i] - sb[a][2 * i]));
-                    v[a][i].y = *reinterpret_cast<const double *>(lutb + ((int)b[2 * i + 1] - sb[a][2 * i + 1]));
-                }
-            }
-        }
-#else
 #pragma unroll
         for (int j = 0; j < OBS_CHUNK; ++j) b[j] = *reinterpret_cast<const uint16_t *>(imgb + (dsc[j] & 0xFFFFu));
 #pragma unroll
@@ -444,7 +408,6 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
                 v[a][i].x = *reinterpret_cast<const double *>(lutb + ((int)b[2 * i] - sb[a][2 * i]));
                 v[a][i].y = *reinterpret_cast<const double *>(lutb + ((int)b[2 * i + 1] - sb[a][2 * i + 1]));
             }
-#endif
         const uint32_t f0b = (uint32_t)(chunk * OBS_PAIRS * 128 + 2 * cx.lane) * 8u;      // byte offset of this lane's first pair
 #define CZ_OBS_STORES(AUX)                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < OBS_PAIRS; ++i)                                                                    \
