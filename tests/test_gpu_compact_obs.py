@@ -176,3 +176,38 @@ def test_fused_rollout_with_a_compact_trajectory(scheme, level, agents, recipes,
             assert np.array_equal(bits(rew[t]), bits(ro)) and np.array_equal(trunc[t], uo)
         assert np.array_equal(strip(env.get_state()), orc.records)
     env.close()
+
+
+def test_ring_runs_with_compact_output_set_on_the_handle():
+    """cz_set_compact_output: ring runs (graph replay; never overlapped) write the codes too; switching it off restores the plain
+    kernels, and the graphs captured before the switch are not replayed with a stale pointer"""
+    from oracle_binding import VecOracle
+    n, A, period, K = 192, 2, 8, 20
+    env = make(n, "coop_test", "example", A, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3", max_steps=25)
+    orc = VecOracle.from_vec_env(env)
+    env.reset(return_obs=False)
+    orc.reset()
+    env.set_overlap(True)                                   # (must not be used for launches that write codes)
+    table = env.obs_table()
+    rng = np.random.default_rng(9)
+    ring_host = rng.integers(0, 5, size=(period, n, A), dtype=np.int32)
+    d_ring = env.alloc((period, n, A), np.int32)
+    d_ring.from_host(ring_host)
+    d_obs, d_codes = env.alloc((n, A, env.F), np.float64), env.alloc((n, A, env.codes_pitch), np.uint8)
+    outs = [env.alloc((n, A), np.float64), env.alloc((n, A), np.uint8), env.alloc((n, A), np.uint8)]
+    step = 0
+    for phase, (codes, obs) in enumerate([(None, d_obs), (d_codes, None), (d_codes, d_obs), (None, d_obs)]):
+        env.set_compact_output(codes)
+        if codes is not None:
+            d_codes.from_host(np.zeros((n, A, env.codes_pitch), dtype=np.uint8))
+        env.step_device_ring(K, d_ring, n * A, period, step % period, obs, *outs)
+        env.sync()
+        for k in range(K):
+            oo, ro, to, uo = orc.step(ring_host[(step + k) % period], k == K - 1)
+        step += K
+        if obs is not None:
+            assert np.array_equal(bits(d_obs.to_host()), bits(oo)), phase
+        if codes is not None:
+            assert np.array_equal(bits(table[d_codes.to_host()[:, :, :env.F]]), bits(oo)), phase
+        assert np.array_equal(strip(env.get_state()), orc.records), phase
+    env.close()
