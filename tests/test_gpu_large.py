@@ -331,6 +331,53 @@ def test_config3_full_size_mixed_levels_whole_recipe_book():
     env.close()
 
 
+def test_config3_full_size_with_despawn_respawn_and_compact_observations():
+    """BASELINE config 3's shape - 65 536 envs on three levels - with despawn / respawn on (spawn areas per level,
+    parsing.py:118-151; round 3 refused mixed levels) and the observation taken as codes: device-pointer steps writing both the
+    float64 rows and the codes, then a fused rollout with a compact trajectory, against the oracle's restatement of the rule
+    (pinned to the reference by tests/golden/spawn_keyed_*.npz) on host threads."""
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    from oracle_binding import ShardedOracle
+    n, A = 65536, 2
+    rid = np.array([[e % 8, (e + 1) % 8] for e in range(n)])
+    env = CookingVecEnv(n, ["coop_test", "coexistence_test", "switch_test"], "example", A, 12, rid, action_scheme="scheme3", num_layouts=256,
+                        auto_reset=True, agent_despawn_rate=0.1, agent_respawn_rate=0.3, grace_period=2, spawn_seed=17)
+    orc = ShardedOracle(env)
+    env.reset(return_obs=False)
+    orc.reset()
+    table, F, Fp = env.obs_table(), env.F, env.codes_pitch
+    d_act = env.alloc((n, A), np.int32)
+    d_obs, d_codes = env.alloc((n, A, F), np.float64), env.alloc((n, A, Fp), np.uint8)
+    d_rew, d_t, d_u = env.alloc((n, A), np.float64), env.alloc((n, A), np.uint8), env.alloc((n, A), np.uint8)
+    rng = np.random.default_rng(35)
+    n_gone = 0
+    for t in range(12):
+        acts = rng.integers(0, 5, size=(n, A), dtype=np.int32)
+        d_act.from_host(acts)
+        env.step_device_compact(d_act, d_codes, d_rew, d_t, d_u, d_obs if t % 2 == 0 else None)
+        env.sync()
+        oo, ro, to, uo = orc.step(acts)
+        assert np.array_equal(bits(table[d_codes.to_host()[:, :, :F]]), bits(oo)), f"decoded observation @ step {t}"
+        if t % 2 == 0:
+            assert np.array_equal(bits(d_obs.to_host()), bits(oo)), f"float64 observation @ step {t}"
+        assert np.array_equal(bits(d_rew.to_host()), bits(ro)) and np.array_equal(d_t.to_host(), to) and np.array_equal(d_u.to_host(), uo), t
+        n_gone += int((((orc.records[:, soa.W_STATUS] >> 8) & 0xF) != 0).sum())
+        del oo
+    assert np.array_equal(strip(env.get_state()), orc.records)
+    assert n_gone > 10000
+    T = 24
+    d_traj = env.alloc((T, n, A, Fp), np.uint8)
+    d_tu = env.alloc((T, n, A), np.uint8)
+    env.rollout_compact(T, 36, 500, d_traj, None, None, None, d_tu)
+    env.sync()
+    oo, ro, to, uo = orc.rollout(T, 36, 500)
+    assert np.array_equal(strip(env.get_state()), orc.records), "records after the fused rollout"
+    assert np.array_equal(bits(table[d_traj.to_host()[-1][:, :, :F]]), bits(oo)), "last observation of the compact trajectory"
+    assert np.array_equal(d_tu.to_host()[-1], uo)
+    assert env.spawn_exhausted() == 0
+    env.close()
+
+
 def test_config5_full_size_four_agents_16x16():
     """BASELINE config 5: 65 536 envs x 4 competing agents on large_16x16 (F = 840, 26.9 KB of observation per env-step)."""
     n = 65536
