@@ -68,3 +68,18 @@ def test_bench_single_gpu_goes_through_the_multi_rank_code():
     d = run(CZ_BENCH_SIMULATE_HANDOFF_TIMEOUT="1")
     assert "gave up waiting" in d["overlap_fallback"] and "timed launches 0 went out as overlapped launches" in d["config"]["api"]
     assert d["value"] > 1e6
+
+
+def test_two_ranks_on_one_device_agree_on_the_outcome():
+    """Two rank processes that both open device 0 (all a one-GPU box can offer): RCCL refuses duplicate devices
+    (ncclInvalidUsage), and the bring-up must end the same way on every rank - a refusal all ranks report, nobody hanging in a
+    collective - or, should an RCCL accept it, with an all-gather that equals the ranks' local statistics."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(repo, "tools", "rccl_two_ranks_one_gpu.py")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    if d["rccl_two_ranks_on_one_device"] == "refused":
+        assert "rank 0:" in d["message"] and "rank 1:" in d["message"]
+    else:
+        assert d["allgather_equals_local_stats"] is True and d["total_env_steps"] > 0
