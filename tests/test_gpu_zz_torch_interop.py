@@ -72,6 +72,15 @@ def test_torch_tensors_on_the_callers_stream():
     assert np.array_equal(bits(obs.cpu().numpy()), bits(o)) and np.array_equal(term.cpu().numpy(), te)
     assert np.array_equal(bits(ret.cpu().numpy()), bits(want_ret))
     assert np.array_equal(env.get_state(), ref.get_state())
+    # the compact observation into a torch tensor, decoded with the table on the GPU: the float64 observation bit for bit
+    codes = torch.empty((n, A, env.codes_pitch), dtype=torch.uint8, device=dev)
+    table = torch.from_numpy(env.obs_table()).to(dev)
+    env.step_device_compact(acts_log[0], codes, rew, term, trunc, obs)
+    torch.cuda.synchronize()
+    decoded = table[codes[..., :env.F].long()]
+    assert torch.equal(decoded.view(torch.int64), obs.view(torch.int64))
+    o, r, te, tr = ref.step(acts_log[0].cpu().numpy())
+    assert np.array_equal(bits(decoded.cpu().numpy()), bits(o))
     with pytest.raises(ValueError):
         env.step_device(acts_log[0].t(), obs, rew, term, trunc)                                  # not contiguous
     env.close()
