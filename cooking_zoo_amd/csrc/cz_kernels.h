@@ -661,6 +661,11 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     // the quotient table is shared by the workgroup: its load joins the other loads of the prologue (no branch here:
     // a branch would split the kernel-argument fetch into several dependent round trips)
     const double lutv = ldg<double>(P.lut, min(threadIdx.x, (unsigned)LUT_SIZE - 1u) * 8u);
+    // The encode's per-lane constant, fetched in front of the record: the wait for the record then covers it.  Fetched behind
+    // the record (as until round 4) its first use - in the image build, behind the reward / termination stores - needed an
+    // `s_waitcnt vmcnt(0)`: gfx950 counts loads and stores in one in-order counter, so that wait also stood for the
+    // acknowledgement of every store issued before it (in a fused launch: the previous step's observation rows).
+    const uint32_t submask = load_submask(P, (int)(threadIdx.x & 63u));
     Lds<CPL> &lds = lds_all[wave];
     Ctx cx{P.W, P.H, P.D, P.W * P.H, lane};
     CZ_STAMP(0);
@@ -725,7 +730,6 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     uint32_t rowv = load_recipe_rows(P, e.recipes, lane);
     uint32_t dsc[OBS_CHUNK];
     if (P.obs) load_desc(P, e.layout, 0, lane, dsc);
-    const uint32_t submask = load_submask(P, lane);
     const int64_t env_global = P.env_id_base + env;
     bool cells_dirty = false, objs_dirty = false, header_dirty = FUSED;
     bool img_objs = true, img_cells = true;                 // which parts of the LDS image the next encode must rebuild

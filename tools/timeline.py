@@ -78,6 +78,9 @@ res = {
     "launches_in_flight_at_a_wave_start": float(np.mean([(first_in[i + 1] < last_out[i]) for i in range(50, K - 1)])) + 1.0,
     "xcc_ids_seen": sorted(int(v) for v in np.unique(xcc[100])),
 }
+# does an env run on the same XCD in every launch?  (workgroup w of a launch goes to XCD w mod 8 when that holds)
+res["envs_on_one_xcc_in_every_launch"] = float(np.mean((xcc == xcc[0:1]).all(axis=0)))
+res["envs_on_xcc_of_workgroup_mod_8"] = float(np.mean((xcc == ((np.arange(N) // 8) % 8)[None, :]).all(axis=0)))
 # per launch: how the wave starts spread (fraction of waves started after x us)
 rel = (t_in - first_in[:, None])[sel]
 res["wave_start_offset_us_percentiles"] = {str(p): us(np.percentile(rel, p)) for p in (10, 50, 90, 99, 100)}
