@@ -348,13 +348,8 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
         decltype(__builtin_amdgcn_make_buffer_rsrc(codes, 0, 0, 0)) rc[NA];
 #pragma unroll
         for (int a = 0; a < NA; ++a) rc[a] = __builtin_amdgcn_make_buffer_rsrc(codes + (size_t)a * (uint32_t)Fp, 0, Fp, 0x00020000);
-        // (the first rounds' descriptor words are kept in registers - fetched behind the prologue, kept across the steps of a fused
-        // rollout - and fetched again when a reset pass has moved the env to another layout)
-        if (pre && pre->layout != e.layout) {
-#pragma unroll
-            for (int r = 0; r < CODES_PREFETCH; ++r) pre->d[r] = load_desc4(P, e.layout, 256u * r + 4u * (uint32_t)cx.lane);
-            pre->layout = e.layout;
-        }
+        // (the first rounds' descriptor words come in registers: fetched behind the prologue or at the top of a fused step, and
+        // fetched again by the caller when a reset pass has moved the env to another layout - `pre` is of e.layout here)
         for (int f0 = 0; f0 < P.F; f0 += 256) {
             const uint32_t f = (uint32_t)f0 + 4u * (uint32_t)cx.lane;                       // this lane's first feature
             uint4_t d;
@@ -721,6 +716,9 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     // write-through stores, which were acknowledged before it published.  So no acquire fence is needed by the hardware - an
     // agent-scope one would invalidate the L2 on every poll - but the compiler must not move the loads up:)
     if (CHAIN) asm volatile("" ::: "memory");
+#ifdef CZ_TIMELINE
+    const uint64_t tl_seen = wall_clock64();        // (an overlapped launch: its predecessor's number has been seen)
+#endif
     // ---- every load of the step is issued here, before anything waits
     if (!FUSED && !CHAIN) av = ldg<int>(P.actions, ((uint32_t)env * (uint32_t)NA + (uint32_t)min(lane, NA - 1)) * 4u);
     double ret = ldrec<double>(chained, retp, ((uint32_t)lane & 3u) * 8u);                                       // running episode return, lane a = agent a
@@ -820,6 +818,17 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         // that T * N * A * 8 fits): the `global_store v, v_off, s[base]` form, no 64-bit per-lane address arithmetic.  The
         // one-step kernels store unconditionally - the host hands them a scratch row for an array the caller does not want.
         const size_t row = FUSED ? ((size_t)t * Pt.N + env) : (size_t)env;
+        // (the compact path's descriptor words were fetched long ago; waiting for them HERE costs nothing, while behind the
+        // stores below the same wait would also stand for those stores' acknowledgement - one counter for loads and stores)
+        if (CODES) {
+            if (cpre.layout != e.layout) {                 // a reset pass has moved the env to another layout
+                cpre.layout = e.layout;
+#pragma unroll
+                for (int r = 0; r < CODES_PREFETCH; ++r) cpre.d[r] = load_desc4(Pt, e.layout, 256u * r + 4u * (uint32_t)lane);
+            }
+#pragma unroll
+            for (int r = 0; r < CODES_PREFETCH; ++r) asm volatile("" :: "v"(cpre.d[r]));
+        }
         {
             const uint32_t oidx = (uint32_t)row * (uint32_t)NA + (uint32_t)lane;          // [row][agent]
             double *const rewards = kp->rewards;
@@ -882,7 +891,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
             typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
             ull2 v;
             v.x = (tl_in & 0xFFFFFFFFull) | ((unsigned long long)hw_id << 32);
-            v.y = (tl_out & 0xFFFFFFFFull) | ((unsigned long long)xcc << 32);
+            v.y = (tl_out & 0xFFFFFFFFull) | ((unsigned long long)(xcc & 15u) << 32) | (((tl_seen - tl_in) & 0xFFFFFFFull) << 36);
             *reinterpret_cast<ull2 *>(tl + 2 * (size_t)env) = v;
         }
     }
