@@ -640,6 +640,9 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     // clock per wave - at its first instruction and behind its last store (for an overlapped launch: behind the publish) - and
     // one 16-byte store of lane 0.  No waits are added in between (unlike the phase stamps of `make prof`).
     const uint64_t tl_in = wall_clock64();
+#ifdef CZ_TL_CLOCK
+    const uint64_t tl_cyc_in = __builtin_readcyclecounter();      // s_memtime: the shader clock
+#endif
 #endif
     Params P = P0;
     P.state = e_state; P.actions = e_actions; P.lut = e_lut; P.N = e_N; P.RW = e_RW; P.W = e_W; P.H = e_H; P.D = e_D;
@@ -660,7 +663,12 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     // the record (as until round 4) its first use - in the image build, behind the reward / termination stores - needed an
     // `s_waitcnt vmcnt(0)`: gfx950 counts loads and stores in one in-order counter, so that wait also stood for the
     // acknowledgement of every store issued before it (in a fused launch: the previous step's observation rows).
-    const uint32_t submask = load_submask(P, (int)(threadIdx.x & 63u));
+    // (The larger instances keep the late fetch, i.e. their round-3 code: their launches are bound by HBM writes, and on the
+    // one box where the two forms differed the wait in front of the encode helped - config 5: 318-323 us per launch with it,
+    // 338-342 us without.  Config 5 varies by +-4 % between boxes and allocations anyway, profiles/r04/cfg5_boxes.txt.)
+    constexpr bool SUBMASK_EARLY = CPL == 1;
+    uint32_t submask = 0;
+    if (SUBMASK_EARLY) submask = load_submask(P, (int)(threadIdx.x & 63u));
     Lds<CPL> &lds = lds_all[wave];
     Ctx cx{P.W, P.H, P.D, P.W * P.H, lane};
     CZ_STAMP(0);
@@ -728,6 +736,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     uint32_t rowv = load_recipe_rows(P, e.recipes, lane);
     uint32_t dsc[OBS_CHUNK];
     if (P.obs) load_desc(P, e.layout, 0, lane, dsc);
+    if (!SUBMASK_EARLY) submask = load_submask(P, lane);
     const int64_t env_global = P.env_id_base + env;
     bool cells_dirty = false, objs_dirty = false, header_dirty = FUSED;
     bool img_objs = true, img_cells = true;                 // which parts of the LDS image the next encode must rebuild
@@ -891,7 +900,11 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
             typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
             ull2 v;
             v.x = (tl_in & 0xFFFFFFFFull) | ((unsigned long long)hw_id << 32);
+#ifdef CZ_TL_CLOCK      // (tools/shader_clock.py: the wave's lifetime in shader-clock cycles instead of the hand-off stamp)
+            v.y = (tl_out & 0xFFFFFFFFull) | ((unsigned long long)(xcc & 15u) << 32) | (((__builtin_readcyclecounter() - tl_cyc_in) & 0xFFFFFFFull) << 36);
+#else
             v.y = (tl_out & 0xFFFFFFFFull) | ((unsigned long long)(xcc & 15u) << 32) | (((tl_seen - tl_in) & 0xFFFFFFFull) << 36);
+#endif
             *reinterpret_cast<ull2 *>(tl + 2 * (size_t)env) = v;
         }
     }
