@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace cz {
 
@@ -1046,27 +1047,53 @@ struct Ops {
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        uint32_t Uq[CPL], S[CPL];
+        uint32_t Uq[CPL];
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {   // D
             const uint32_t st = NS[e.cell[q] & CELL_TYPE];
             Uq[q] = U[lane + 64 * q] | ((lane + 64u * q) < (uint32_t)cx.C ? st : 0u);
-            S[q] = 0u;
         }
-#pragma nounroll
-        for (int r = 0; r < R; ++r) {     // E
-            if (!((which >> r) & 1u)) continue;
-            const int n = (int)(rdl(rowv, 9 * r) & 0xFFu);
-#pragma nounroll
-            for (int j = n - 1; j >= 0; --j) {
-                const uint32_t need = (rdl(rowv, 9 * r + 1 + j) & 0xFFu) << (8 * r), bit = 1u << (8 * r + j);
+        // E.  A wave that gets here is, more often than not, the last one of its launch (0.3 % of the waves of the bench
+        // workload; a launch lasts as long as its slowest wave), so this is written for latency, not for instruction count: no
+        // loops, no branches, no lane reads inside the dependent chain.  Every recipe has its own 8-bit S (a node's children
+        // are nodes of the same recipe), so the chains of different recipes are independent and interleave; nodes run from 7
+        // down to 0 whatever the graph's size (rows are zero-padded: a node that does not exist has no U bit and adds
+        // nothing), three dependent vector instructions per node: S & need, == need, select(S, S | U & bit).  Recipes that are
+        // not to be evaluated (`which`) get U = 0.  (Until round 4: a loop over the recipes and their nodes with two lane reads,
+        // a shift and a branch per node in front of the same arithmetic: 0.9 us for two five-node graphs, now ~0.3.)
+        uint32_t all = 0u;
+        const auto chains = [&](auto nr_tag, int r0) {
+            constexpr int NR = decltype(nr_tag)::value;
+            uint32_t need[NR][MAX_NODES];
 #pragma unroll
-                for (int q = 0; q < CPL; ++q) S[q] |= ((S[q] & need) == need) ? (Uq[q] & bit) : 0u;
-            }
-        }
-        uint32_t all = S[0];
+            for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int q = 1; q < CPL; ++q) all |= S[q];
+                for (int j = 0; j < MAX_NODES; ++j) need[r][j] = rdl(rowv, 9 * (r0 + r) + 1 + j) & 0xFFu;
+            uint32_t Ur[NR][CPL], S[NR][CPL];
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    const uint32_t on = 0u - ((which >> (r0 + r)) & 1u);
+                    Ur[r][q] = (Uq[q] >> (8 * (r0 + r))) & 0xFFu & on;
+                    S[r][q] = 0u;
+                }
+#pragma unroll
+            for (int j = MAX_NODES - 1; j >= 0; --j)
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) {
+                        const uint32_t with = S[r][q] | (Ur[r][q] & (1u << j));
+                        S[r][q] = ((S[r][q] & need[r][j]) == need[r][j]) ? with : S[r][q];
+                    }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) all |= S[r][q] << (8 * (r0 + r));
+        };
+        chains(std::integral_constant<int, 2>{}, 0);
+        if (R > 2) chains(std::integral_constant<int, 2>{}, 2);
         return wave_or(all);              // F
     }
     static __device__ __forceinline__ uint32_t recipe_marks_wide(const E &e, const Ctx &cx, const uint32_t *__restrict__ row,

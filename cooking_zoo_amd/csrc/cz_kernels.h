@@ -424,6 +424,9 @@ struct StepOut {
     bool stepped, finished;        // a world step was executed / it ended the episode
     bool header;                   // a header word other than `t` changed (marks, status, episode, layout)
     uint32_t gone;                 // despawn / respawn: bit a = agent a left in this step (reported truncated once)
+#ifdef CZ_TIMELINE
+    uint32_t dbg;                  // timeline build: 1 an object moved or changed, 2 recipe graphs re-evaluated, 4 marks changed, 8 somebody interacted
+#endif
 };
 
 // One accumulated_step (cooking_env.py:243-269) of one env held in registers.
@@ -433,6 +436,9 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
     using O = Ops<OPL, CPL, NA, SCHEME>;
     o.myrew = 0.0;
     o.term = 0; o.trunc = 0; o.stepped = false; o.finished = false; o.header = false; o.gone = 0u;
+#ifdef CZ_TIMELINE
+    o.dbg = 0u;
+#endif
     // P.auto_reset: bit 0 = next-step auto-reset, bit 1 = agent despawn / respawn is on (cz_set_spawn)
     const bool spawning = (P.auto_reset & 2) != 0;
     const SpawnCfg *const spawn_cfg = reinterpret_cast<const SpawnCfg *>(reinterpret_cast<const char *>(P.lut) + SPAWN_CFG_OFFSET);
@@ -561,6 +567,9 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
                 const uint32_t which = any & (dt.statechg != 0u ? 0xFu : (any >> 4)) & ((1u << P.R) - 1u);   // the recipes to re-evaluate
                 if (which) {
                     CZ_SETPRIO(3);
+#ifdef CZ_TIMELINE
+                    o.dbg |= 2u;
+#endif
                     const uint32_t fresh = O::recipe_marks_cells(e, cx, rowv, which, P.R, lds.locs);
                     CZ_STAMP(9);
                     const uint32_t bytes = ((which * 0x204081u) & 0x01010101u) * 0xFFu;    // bit r -> byte r
@@ -594,6 +603,9 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
         }
         e.marks = after;
         o.header |= after != before;
+#ifdef CZ_TIMELINE
+        o.dbg |= (dt.touched ? 1u : 0u) | (after != before ? 4u : 0u) | (dt.interacted ? 8u : 0u);
+#endif
         // recipe roots are bit 0 of each marks byte
         const uint32_t roots = after & 0x01010101u & (P.R >= 4 ? 0xFFFFFFFFu : ((1u << (8 * P.R)) - 1u));
         done = P.end_all ? (__popc(roots) == P.R) : (roots != 0u);
@@ -756,6 +768,9 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     }
 
     const int T = FUSED ? P.T : 1;
+#ifdef CZ_TIMELINE
+    uint32_t tl_dbg = 0u;
+#endif
     // a fused rollout over caller-supplied actions (cz_rollout_actions: [T][N][A] int32): step t's action words are loaded one
     // step ahead, so the round trip hides behind the previous step's work
     const uint32_t act_lane = ((uint32_t)env * (uint32_t)NA + (uint32_t)min(lane, NA - 1)) * 4u;
@@ -796,6 +811,9 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         Dirty dt{};
         StepOut o;
         step_env<OPL, CPL, NA, SCHEME>(Pt, (unsigned)offsetof(StepArgsMirror, p), e, cx, acts, env_global, rowv, lds, dsc, dt, o);
+#ifdef CZ_TIMELINE
+        tl_dbg |= o.dbg;
+#endif
 #if defined(CZ_ABLATE)
         if (Pt.stop == 2 || Pt.stop == 3) return;
 #endif
@@ -899,7 +917,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         if (tl && lane == 0) {
             typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
             ull2 v;
-            v.x = (tl_in & 0xFFFFFFFFull) | ((unsigned long long)hw_id << 32);
+            v.x = (tl_in & 0xFFFFFFFFull) | ((unsigned long long)(hw_id & 0xFFFFu) << 32) | ((unsigned long long)tl_dbg << 48);
 #ifdef CZ_TL_CLOCK      // (tools/shader_clock.py: the wave's lifetime in shader-clock cycles instead of the hand-off stamp)
             v.y = (tl_out & 0xFFFFFFFFull) | ((unsigned long long)(xcc & 15u) << 32) | (((__builtin_readcyclecounter() - tl_cyc_in) & 0xFFFFFFFull) << 36);
 #else

@@ -30,6 +30,7 @@ names = ["prologue+loads", "agents", "progress", "rewards/flags", "outputs", "ob
 MODE = sys.argv[2] if len(sys.argv) > 2 else "random"
 TICK_NS = 10.0                      # s_memrealtime: 100 MHz
 acc = []
+inner, frac = [], []
 spread, endspread, evt_us = [], [], []
 for it in range(60):
     d_act.from_host(rng.integers(0, 5, size=(N, 2), dtype=np.int32) if MODE == "random" else np.zeros((N, 2), np.int32))
@@ -39,9 +40,16 @@ for it in range(60):
     L.cz_timer_stop(h, C.byref(ms))
     if it >= 10:
         evt_us.append(ms.value * 1e3)
-    s = stamps.to_host().astype(np.int64)[:, :8]
+    s_all = stamps.to_host().astype(np.int64)
+    s = s_all[:, :8]
     if it >= 10:
         acc.append(np.diff(s, axis=1))
+        # inside the reward phase (stamps 8, 9, 10 are written only by waves that got that far in THIS launch)
+        ev = (s_all[:, 8] > s_all[:, 3]) & (s_all[:, 9] > s_all[:, 8]) & (s_all[:, 10] > s_all[:, 9]) & (s_all[:, 10] < s_all[:, 4])
+        inner.append(np.stack([s_all[ev, 8] - s_all[ev, 3], s_all[ev, 9] - s_all[ev, 8], s_all[ev, 10] - s_all[ev, 9], s_all[ev, 4] - s_all[ev, 10],
+                               s_all[ev, 2] - s_all[ev, 1]], axis=1))
+        touched = (s_all[:, 8] > s_all[:, 3]) & (s_all[:, 8] < s_all[:, 4])
+        frac.append((touched.mean(), ev.mean()))
         spread.append(s[:, 0].max() - s[:, 0].min())
         endspread.append(s[:, 7].max() - s[:, 0].min())
 d = np.concatenate(acc)
@@ -64,3 +72,10 @@ worst = np.stack([a[a.sum(axis=1).argmax()] for a in acc])
 for i, n in enumerate(names):
     print(f"  {n:16s} {worst[:, i].mean():8.0f}")
 print("  total", worst.sum(axis=1).mean())
+
+if inner:
+    I = np.concatenate(inner)
+    f = np.array(frac).mean(axis=0)
+    print("waves that re-evaluate recipe graphs: %.1f %% of all (an object changed: %.1f %%); their reward phase, median ticks: filter %.0f | "
+          "recipe_marks_cells %.0f | marks -> rewards %.0f | flags %.0f;  their agents phase %.0f" % (
+              100 * f[1], 100 * f[0], *[np.median(I[:, k]) for k in range(4)], np.median(I[:, 4])))
