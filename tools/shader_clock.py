@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""At what shader clock do the step kernels run?  Timeline build with -DCZ_TL_CLOCK (libcz_tlclk.so): every wave reports its
+"""At what shader clock do the step kernels run?  Needs `make -C cooking_zoo_amd/csrc tlclock` (libcz_tlclk.so: the timeline build with -DCZ_TL_CLOCK): every wave reports its
 lifetime on the 100 MHz device clock and in shader-clock cycles (s_memtime).
     python3 tools/shader_clock.py [N=4096] [K=2000] [overlap=0]"""
 import os, sys
