@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: BASELINE configs 3 / 5 / config-4 shard, this tree against .ab/prev (the round-3 tree), interleaved
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 O=gpurun_out/r04; mkdir -p $O
 for rep in 1 2; do
   for c in ${CASES:-cfg5 cfg3 cfg4_shard}; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, ablation build (make ablate): dynamic instruction count of each phase = difference between successive CZ_STOP
 # truncations.   usage: bash tools/abl.sh [steps=400] [random|zero]
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 export CZ_LIB=$GRAFT_REPO_ROOT/cooking_zoo_amd/csrc/libcookingzoo_hip_ablate.so
 STEPS=${1:-400}; MODE=${2:-random}
 for m in 1 2 3 4 5 6 7; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the default bench line with every leg, summarised (and kept under gpurun_out/r04/)
 TAG=${1:-x}
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 O=gpurun_out/r04; mkdir -p $O
 timeout 900 python3 bench.py --no-cpu-baseline > $O/bench_full_$TAG.json 2>$O/bench_full_$TAG.err
 python3 - <<PY

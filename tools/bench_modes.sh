@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the headline line under the three ways of issuing a K-step region (overlapped launches, graph replay, direct launches)
 # at the driver's K = 20 and at K = 2000, plus the default line with every leg
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 O=gpurun_out/r04; mkdir -p $O
 show() { python3 -c "
 import json,sys

@@ -4,7 +4,7 @@
 # The counter passes run with CZ_CHAIN=0: a --pmc run executes one kernel at a time in an order of its own, and an
 # overlapped launch that is run before its predecessor waits for it until the hand-off deadline.
 # Every profiled command runs under `timeout`: a profiler-side abort must not be able to hold the box.
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 TAG=${1:-cur}
 O=gpurun_out/prof_$TAG
 TRACE_ARGS=${TRACE_ARGS:---steps 400 --warmup 40 --repeats 5 --no-extras}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: everything profiles/r04/ holds, from one box.  usage: bash tools/collect_r04.sh   (results under gpurun_out/r04_final/)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 O=gpurun_out/r04_final
 rm -rf $O; mkdir -p $O
 # 1. device-clock timelines (timeline library): boundary-ordered and overlapped, bench workload

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: what the compute units are busy with during a 4096-env launch of the one-step kernel (bench workload, launch-boundary
 # ordering): issue-cycle counters of the scalar unit, the vector ALUs, LDS and memory instructions, in separate --pmc passes.
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 O=gpurun_out/r04/issue_pmc; rm -rf $O; mkdir -p $O
 i=0
 for set in "SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_CYCLES GRBM_GUI_ACTIVE" \

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: bash tools/pmc_issue.sh TAG   -- who uses the issue slots of the step kernel (GPU box); two SQ passes of 8 counters
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 TAG=${1:-x}
 mkdir -p gpurun_out/pmci1_$TAG gpurun_out/pmci2_$TAG
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*" | sort -u | tr '\n' ' ' > gpurun_out/r02/sq_counters.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: HBM traffic counters (separate --pmc passes, as the microarch guide prescribes) and kernel trace of the one-step and the
 # fused kernel at large batches.  usage: bash tools/pmc_large.sh TAG case...   (cases of tools/bench_configs.py: cfg3 cfg5 cfg4_shard cfg2_64k)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 TAG=${1:-x}; shift
 CASES=${@:-cfg3}
 O=gpurun_out/pmc_large_$TAG

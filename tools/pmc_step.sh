@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: bash tools/pmc_step.sh TAG   -- PMC instruction counts + timing of the bench step kernel (GPU box)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 TAG=${1:-x}
 mkdir -p gpurun_out/pmc_$TAG gpurun_out/pmcn_$TAG
 CZ_CHAIN=0 timeout 240 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_LDS --output-format csv -d gpurun_out/pmc_$TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1

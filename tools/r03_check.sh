@@ -4,7 +4,7 @@
 #  without it only this tree is measured.  For A/Bs of single kernels see tools/ab_libs.sh / tools/ab_overlap.sh with CZ_LIB.)
 # usage: bash tools/r03_check.sh TAG [pytest -k expression]
 TAG=${1:-x}; K=${2:-"parity or rollout or fuzz or api"}
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 mkdir -p gpurun_out/r03
 python -m pytest tests -m gpu -x -q -k "$K" 2>&1 | tail -8 > gpurun_out/r03/tests_$TAG.log
 bash tools/interact_probe.sh > gpurun_out/r03/ip_$TAG.txt 2>&1
