@@ -1009,6 +1009,7 @@ struct Ops {
         // would otherwise be hoisted to the top of the kernel and live in scalar register pairs through every step)
         uint32_t lane = (uint32_t)cx.lane;
         asm volatile("" : "+v"(lane));
+        which &= (1u << R) - 1u;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) U[lane + 64 * q] = 0u;
         NK[lane] = 0u;
@@ -1056,44 +1057,36 @@ struct Ops {
         // E.  A wave that gets here is, more often than not, the last one of its launch (0.3 % of the waves of the bench
         // workload; a launch lasts as long as its slowest wave), so this is written for latency, not for instruction count: no
         // loops, no branches, no lane reads inside the dependent chain.  Every recipe has its own 8-bit S (a node's children
-        // are nodes of the same recipe), so the chains of different recipes are independent and interleave; nodes run from 7
+        // are nodes of the same recipe), so the chains of different recipes are independent; nodes run from 7 (or 3)
         // down to 0 whatever the graph's size (rows are zero-padded: a node that does not exist has no U bit and adds
-        // nothing), three dependent vector instructions per node: S & need, == need, select(S, S | U & bit).  Recipes that are
-        // not to be evaluated (`which`) get U = 0.  (Until round 4: a loop over the recipes and their nodes with two lane reads,
+        // nothing), three dependent vector instructions per node: S & need, == need, select(S, S | U & bit).  Only the recipes
+        // in `which` run (a wave-uniform branch each), graphs of up to four nodes run four levels.  (Until round 4: a loop over the recipes and their nodes with two lane reads,
         // a shift and a branch per node in front of the same arithmetic: 0.9 us for two five-node graphs, now ~0.3.)
         uint32_t all = 0u;
-        const auto chains = [&](auto nr_tag, int r0) {
-            constexpr int NR = decltype(nr_tag)::value;
-            uint32_t need[NR][MAX_NODES];
+        const auto chain = [&](int r, auto from_tag) {           // nodes FROM - 1 .. 0 of recipe r
+            constexpr int FROM = decltype(from_tag)::value;
+            uint32_t need[FROM];
 #pragma unroll
-            for (int r = 0; r < NR; ++r)
+            for (int j = 0; j < FROM; ++j) need[j] = rdl(rowv, 9 * r + 1 + j) & 0xFFu;
+            uint32_t Ur[CPL], S[CPL];
 #pragma unroll
-                for (int j = 0; j < MAX_NODES; ++j) need[r][j] = rdl(rowv, 9 * (r0 + r) + 1 + j) & 0xFFu;
-            uint32_t Ur[NR][CPL], S[NR][CPL];
+            for (int q = 0; q < CPL; ++q) { Ur[q] = (Uq[q] >> (8 * r)) & 0xFFu; S[q] = 0u; }
 #pragma unroll
-            for (int r = 0; r < NR; ++r)
+            for (int j = FROM - 1; j >= 0; --j)
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
-                    const uint32_t on = 0u - ((which >> (r0 + r)) & 1u);
-                    Ur[r][q] = (Uq[q] >> (8 * (r0 + r))) & 0xFFu & on;
-                    S[r][q] = 0u;
+                    const uint32_t with = S[q] | (Ur[q] & (1u << j));
+                    S[q] = ((S[q] & need[j]) == need[j]) ? with : S[q];
                 }
 #pragma unroll
-            for (int j = MAX_NODES - 1; j >= 0; --j)
-#pragma unroll
-                for (int r = 0; r < NR; ++r)
-#pragma unroll
-                    for (int q = 0; q < CPL; ++q) {
-                        const uint32_t with = S[r][q] | (Ur[r][q] & (1u << j));
-                        S[r][q] = ((S[r][q] & need[r][j]) == need[r][j]) ? with : S[r][q];
-                    }
-#pragma unroll
-            for (int r = 0; r < NR; ++r)
-#pragma unroll
-                for (int q = 0; q < CPL; ++q) all |= S[r][q] << (8 * (r0 + r));
+            for (int q = 0; q < CPL; ++q) all |= S[q] << (8 * r);
         };
-        chains(std::integral_constant<int, 2>{}, 0);
-        if (R > 2) chains(std::integral_constant<int, 2>{}, 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (!((which >> r) & 1u)) continue;                  // (wave-uniform: `which` has no bits past R)
+            if ((rdl(rowv, 9 * r) & 0xFFu) > 4u) chain(r, std::integral_constant<int, MAX_NODES>{});
+            else chain(r, std::integral_constant<int, 4>{});
+        }
         return wave_or(all);              // F
     }
     static __device__ __forceinline__ uint32_t recipe_marks_wide(const E &e, const Ctx &cx, const uint32_t *__restrict__ row,
