@@ -274,6 +274,37 @@ def leg_fused_actions(env, K):
         d_act.free()
 
 
+def leg_ring_fused(env, K, d_obs, d_rew, d_term, d_trunc):
+    """The headline's call - cz_step_device_ring over a ring of action slots, outputs in place - with cz_set_ring_fused(h, 1): the K
+    steps of a region go out as fused launches over the ring's own rows (one per stretch of consecutive slots) instead of one
+    launch per step.  Same final state, outputs and statistics (tests/test_gpu_ring_fused.py); regions of the driver's K and of
+    2000 steps, wall clock between synchronisations like the headline's regions."""
+    from cooking_zoo_amd import _native
+    L, h = _native.lib(), env._h
+    N, A, period = env.num_envs, env.num_agents, 64
+    d_ring = env.alloc((period, N, A), np.int32)
+    outs = (d_obs.ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr)
+    was = env.set_ring_fused(True)
+    try:
+        d_ring.from_host(np.random.default_rng(13).integers(0, env.n_actions, size=(period, N, A), dtype=np.int32))
+        out = {"api": "cz_step_device_ring after cz_set_ring_fused(h, 1): fused launches over the ring's rows, outputs written in place"}
+        for k in sorted({int(K), 2000}):
+            _native.check(h, L.cz_step_device_ring(h, k, d_ring.ptr, N * A, period, 0, *outs))
+            env.sync()
+            times = []
+            for rep in range(7):
+                t0 = time.perf_counter()
+                _native.check(h, L.cz_step_device_ring(h, k, d_ring.ptr, N * A, period, 0, *outs))
+                env.sync()
+                times.append(time.perf_counter() - t0)
+            dt = sorted(times)[len(times) // 2]
+            out["K=%d" % k] = {"us_per_step": dt * 1e6 / k, "env_steps_per_s": N * k / dt}
+        return out
+    finally:
+        env.set_ring_fused(was)
+        d_ring.free()
+
+
 def cooking_policy_workload(device_id, K=512):
     """The one-step kernel under a policy that cooks: the reference's heuristic agent's action sequences (golden fixtures
     cfg2_coop_2agents, episodes that end with a delivered dish), every env on one of those worlds at its own phase of the
@@ -801,6 +832,7 @@ def worker_body(args, rdzv, overlap, note):
             # An extra leg must never be able to lose the headline measured above: whatever it raises is recorded under its key.
             line["fused_actions"] = guarded(leg_fused_actions, env, K)
             line["fused_compact"] = guarded(leg_fused_compact, env, K)
+            line["ring_fused"] = guarded(leg_ring_fused, env, K, d_obs, d_rew, d_term, d_trunc)
             line["closed_loop"] = guarded(leg_closed_loop, env, d_obs, d_rew, d_term, d_trunc)
             line["closed_loop_compact"] = guarded(leg_closed_loop_compact, env, d_rew, d_term, d_trunc)
             line["cooking_policy"] = guarded(leg_cooking_policy, local_rank)

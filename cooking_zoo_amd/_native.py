@@ -74,6 +74,8 @@ SYMBOLS = [
     ("cz_launch_counts", C.c_int, [_VP, C.POINTER(_I64), C.POINTER(_I64), _I32]),
     ("cz_chain_counts", C.c_int, [_VP, C.POINTER(_I64), _I32]),
     ("cz_set_overlap", C.c_int, [_VP, _I32]),
+    ("cz_set_ring_fused", C.c_int, [_VP, _I32]),
+    ("cz_ring_fused_steps", C.c_int64, [_VP, _I32]),
     ("cz_overlap_limit", _I64, [_VP]),
     ("cz_last_marks", C.c_int, [_VP, _VP]),
     ("cz_set_stream", C.c_int, [_VP, _VP]),

@@ -234,6 +234,8 @@ struct cz_handle_s {
     int32_t tl_cap = 0;
     int64_t tl_count = 0;
     bool graphs_enabled = true;    // CZ_GRAPHS=0: cz_step_device_ring launches everything directly
+    bool ring_fused = false;       // cz_set_ring_fused: runs of cz_step_device_ring / _many go out as fused launches (outputs in place)
+    int64_t n_ring_fused_steps = 0;
     int32_t ring_prefix = 0;       // CZ_RING_PREFIX: steps of a cz_step_device_ring call launched directly in front of its first graph
     size_t zero_copy_bytes = (size_t)256 << 10;   // cz_step: batches whose buffers fit use the pinned device-mapped block (CZ_ZERO_COPY_BYTES)
     cz_stats *d_gather = nullptr;
@@ -282,7 +284,7 @@ static int chain_recover(cz_handle h) {
     *(volatile uint32_t *)h->h_chain_err = 0;
     return 0;
 }
-extern "C" int32_t cz_abi_version(void) { return 5; }
+extern "C" int32_t cz_abi_version(void) { return 6; }
 // diagnostic builds only (tools/phase_profile.py): where the kernels write their s_memtime stamps
 extern "C" int cz_debug_set_stamps(cz_handle h, void *d_buf) {
     if (!h) return 1;
@@ -1109,6 +1111,8 @@ extern "C" int cz_obs_table(cz_handle h, double *table) {
 }
 extern "C" const void *cz_obs_table_device(cz_handle h) { return h ? (const void *)h->d_lut : nullptr; }
 
+static bool ring_fusable(cz_handle h, const Params &P, int32_t K, int64_t stride);
+static int launch_ring_fused(cz_handle h, Params &P, int32_t K, const int32_t *d_ring, int64_t stride, int32_t period, int32_t first_slot);
 // K consecutive steps, one launch each, issued from C: step k reads actions d_actions + k * action_stride (int32 units,
 // wrapping every `action_period` steps) and overwrites the same output buffers.  Same work as K cz_step_device calls
 // without K trips through the host language.
@@ -1121,6 +1125,7 @@ extern "C" int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_acti
     Params P = h->P;
     P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
     P.actions = d_actions;
+    if (ring_fusable(h, P, K, action_stride)) return launch_ring_fused(h, P, K, d_actions, action_stride, action_period, 0);   // cz_set_ring_fused
     if (K >= 2 && chainable(h, P)) return launch_chain(h, P, K, d_actions, action_stride, action_period, 0);   // cz_set_overlap
     for (int32_t k = 0; k < K; ++k) {
         P.actions = d_actions + (int64_t)(k % action_period) * action_stride;
@@ -1188,6 +1193,29 @@ static int ring_graph(cz_handle h, Params &P, const int32_t *d_ring, int64_t str
     out = ge;
     return 0;
 }
+// cz_set_ring_fused: the run as fused launches over the ring's own action rows (cz_rollout_actions' kernel, every step's outputs
+// written in place), one launch per stretch of consecutive slots.  Needs densely packed slots (stride = num_envs * num_agents).
+static bool ring_fusable(cz_handle h, const Params &P, int32_t K, int64_t stride) {
+    return h->ring_fused && K >= 2 && !h->ktime && !P.codes && stride == (int64_t)P.N * P.A;
+}
+static int launch_ring_fused(cz_handle h, Params &P, int32_t K, const int32_t *d_ring, int64_t stride, int32_t period, int32_t first_slot) {
+    // (the kernel addresses the action rows with 32-bit byte offsets from the first row of the launch)
+    const int64_t max_T = (int64_t)(0xFFFFFFFFull / ((uint64_t)P.N * (uint64_t)P.A * 4ull));
+    int32_t k = 0;
+    while (k < K) {
+        const int32_t slot = (int32_t)(((int64_t)first_slot + k) % period);
+        int64_t run = K - k;
+        if (run > period - slot) run = period - slot;
+        if (run > max_T) run = max_T;
+        Params Q = P;
+        Q.actions = d_ring + (int64_t)slot * stride;
+        Q.T = (int32_t)run; Q.seed = 0; Q.step0 = 1u;          // bit 0: outputs in place
+        if (launch_step(h, Q, nullptr, true)) return 1;
+        k += (int32_t)run;
+    }
+    h->n_ring_fused_steps += K;
+    return 0;
+}
 // walks the run [first_slot, first_slot + K) piece by piece; launch = false only builds the graphs
 static int ring_walk(cz_handle h, int32_t K, const int32_t *d_ring, int64_t stride, int32_t period, int32_t first_slot, double *d_obs,
                      double *d_rewards, uint8_t *d_term, uint8_t *d_trunc, bool launch) {
@@ -1196,6 +1224,7 @@ static int ring_walk(cz_handle h, int32_t K, const int32_t *d_ring, int64_t stri
     P.actions = d_ring;
     // (overlapped runs are launched directly: captured into a graph as two parallel chains they still overlap, but replay
     // costs 0.2 us per launch more and a 20-step region 1 us per step more than direct launches on two streams)
+    if (ring_fusable(h, P, K, stride)) return launch ? launch_ring_fused(h, P, K, d_ring, stride, period, first_slot) : 0;
     if (K >= 2 && chainable(h, P)) return launch ? launch_chain(h, P, K, d_ring, stride, period, first_slot) : 0;
     const bool graphs = ring_select(h, d_ring, stride, period, d_obs, d_rewards, d_term, d_trunc);
     int32_t k = 0;
@@ -1292,6 +1321,22 @@ extern "C" int cz_set_overlap(cz_handle h, int32_t enabled) {
         owner.compare_exchange_strong(me, nullptr);
     }
     return was;
+}
+// Runs of cz_step_device_ring / cz_step_device_many as FUSED launches (opt-in): the K steps of a run whose action slots are densely
+// packed go out as one launch per stretch of consecutive slots, the env state staying in registers across the steps and every
+// step's outputs written to the caller's [N][A] buffers in place - the same final state, outputs and statistics as K launches,
+// without launch boundaries or sequence words.  Returns the previous setting.
+extern "C" int cz_set_ring_fused(cz_handle h, int32_t enabled) {
+    if (!h) { fail(nullptr, "null handle"); return -1; }
+    const int was = h->ring_fused ? 1 : 0;
+    h->ring_fused = enabled != 0;
+    return was;
+}
+extern "C" int64_t cz_ring_fused_steps(cz_handle h, int32_t reset) {
+    if (!h) return 0;
+    const int64_t n = h->n_ring_fused_steps;
+    if (reset) h->n_ring_fused_steps = 0;
+    return n;
 }
 // how many step kernels of this handle went out as overlapped launches (cz_step_device_ring only); reset != 0 zeroes it
 extern "C" int cz_chain_counts(cz_handle h, int64_t *chained_kernels, int32_t reset) {

@@ -844,7 +844,10 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         // ---- outputs of this step.  One wave-uniform base pointer per array and a 32-bit per-lane offset (cz_rollout checks
         // that T * N * A * 8 fits): the `global_store v, v_off, s[base]` form, no 64-bit per-lane address arithmetic.  The
         // one-step kernels store unconditionally - the host hands them a scratch row for an array the caller does not want.
-        const size_t row = FUSED ? ((size_t)t * Pt.N + env) : (size_t)env;
+        // (mode 2 with P.step0 & 1 - cz_set_ring_fused: the steps of an action ring fused into one launch - writes every step's
+        // outputs to row `env`, like the one-step launches it stands in for; a wave's stores to one address keep their order)
+        const bool in_place = EXT && (Pt.step0 & 1u) != 0u;
+        const size_t row = FUSED ? ((size_t)(in_place ? 0 : t) * Pt.N + env) : (size_t)env;
         // (the compact path's descriptor words were fetched long ago; waiting for them HERE costs nothing, while behind the
         // stores below the same wait would also stand for those stores' acknowledgement - one counter for loads and stores)
         if (CODES) {

@@ -532,6 +532,19 @@ class CookingVecEnv:
     def overlap_limit(self):
         return int(_native.lib().cz_overlap_limit(self._h))
 
+    def set_ring_fused(self, enabled=True):
+        """Runs of two or more steps of `step_device_ring` whose action slots are densely packed (`action_stride == num_envs *
+        num_agents`) go out as fused launches - one per stretch of consecutive slots, the state in registers across the steps,
+        every step's outputs written in place: the same final state, outputs and statistics as one launch per step, at the cost
+        per step of a fused rollout (4.0-4.3 instead of 5.1-5.8 us at 4096 envs).  Open loop only.  Returns the previous setting."""
+        rc = _native.lib().cz_set_ring_fused(self._h, 1 if enabled else 0)
+        if rc < 0:
+            raise _native.NativeError((_native.lib().cz_last_error(self._h) or b"cz_set_ring_fused failed").decode())
+        return bool(rc)
+
+    def ring_fused_steps(self, reset=False):
+        return int(_native.lib().cz_ring_fused_steps(self._h, 1 if reset else 0))
+
     def set_stream(self, stream=None):
         """Order this env's device work on the caller's HIP stream: an int / ctypes pointer, or an object with a
         `cuda_stream` attribute such as torch.cuda.current_stream().  None = the env's own stream."""

@@ -210,6 +210,18 @@ int cz_step_device_ring(cz_handle h, int32_t K, const int32_t *d_ring, int64_t a
 int cz_ring_prepare(cz_handle h, int32_t K, const int32_t *d_ring, int64_t action_stride, int32_t action_period,
                     int32_t first_slot, double *d_obs, double *d_rewards, uint8_t *d_terminations, uint8_t *d_truncations);
 
+/* FUSED RING RUNS (opt-in).  With cz_set_ring_fused(h, 1), a run of two or more steps of cz_step_device_ring / _many whose action
+ * slots are densely packed (action_stride == num_envs * num_agents) goes out as ONE launch per stretch of consecutive slots
+ * (cut where the ring wraps): cz_rollout_actions' kernel over the ring's own rows, the env state in registers across the
+ * steps, every step's observation / rewards / flags written IN PLACE to the [N][A]... buffers of the call.  Afterwards state,
+ * output buffers and statistics are bit for bit what K one-step launches leave (cooking_env.py:243-269 K times) - at the cost
+ * per step of a fused rollout, without launch boundaries, second streams or sequence words.  Open loop by nature (the actions
+ * of the whole run are read by one launch).  Takes precedence over cz_set_overlap; runs with other strides, a compact
+ * output (cz_set_compact_output) or kernel timing switched on are issued as before.  Returns the previous setting, -1 for a
+ * null handle; cz_ring_fused_steps: env steps issued this way so far (reset != 0: zero the count after reading). */
+int cz_set_ring_fused(cz_handle h, int32_t enabled);
+int64_t cz_ring_fused_steps(cz_handle h, int32_t reset);
+
 /* How many step kernels cz_step_device_ring has replayed from graphs / launched directly on this handle so far
  * (reset != 0: zero both after reading).  bench.py describes its run from these numbers. */
 int cz_launch_counts(cz_handle h, int64_t *graph_kernels, int64_t *direct_kernels, int32_t reset);

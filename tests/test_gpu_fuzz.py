@@ -146,6 +146,18 @@ def run_case(i, kw, seed, extra):
     assert np.array_equal(strip(env.get_state()), orc.records), ctx
     assert np.array_equal(bits(d_obs.to_host()), bits(oo)) and np.array_equal(bits(d_rew.to_host()[0]), bits(ro)), ctx
     assert np.array_equal(d_term.to_host()[0], to) and np.array_equal(d_trunc.to_host()[0], uo), ctx
+    # ... and the same kind of run as fused launches over the ring's rows (cz_set_ring_fused: outputs written in place)
+    env.set_ring_fused(True)
+    K2, first2 = int(rng.integers(2, 40)), int(rng.integers(period))
+    _native.check(env._h, _native.lib().cz_step_device_ring(env._h, K2, d_ring.ptr, n * A, period, first2, d_obs.ptr, d_rew.ptr,
+                                                            d_term.ptr, d_trunc.ptr))
+    env.sync()
+    assert env.ring_fused_steps() == K2, ctx
+    for k in range(K2):
+        oo, ro, to, uo = orc.step(ring_host[(first2 + k) % period], k == K2 - 1)
+    assert np.array_equal(strip(env.get_state()), orc.records), ctx
+    assert np.array_equal(bits(d_obs.to_host()), bits(oo)) and np.array_equal(bits(d_rew.to_host()[0]), bits(ro)), ctx
+    assert np.array_equal(d_term.to_host()[0], to) and np.array_equal(d_trunc.to_host()[0], uo), ctx
     st = env.stats()
     assert st["episodes"] == int(orc.records[:, soa.W_EPISODE].sum()) + int((orc.records[:, soa.W_STATUS] & 1).sum()), ctx
     env.close()

@@ -1,0 +1,156 @@
+"""GPU: cz_set_ring_fused - a run of cz_step_device_ring / cz_step_device_many issued as fused launches over the ring's own action
+rows, every step's outputs written in place - against the oracle stepped over the same slots and against the same run issued as one
+launch per step: final state, final outputs and statistics bit for bit, on every kernel instance and scheme, with ring wrap-around,
+on-device auto-reset inside the launches, negative actions, despawn / respawn, and the cases that must fall back (other strides,
+a compact output)."""
+import numpy as np
+import pytest
+
+from cooking_zoo_amd import _native, soa
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def strip(recs):
+    r = recs.copy()
+    r[:, soa.RET_WORD0:soa.RET_WORD0 + 8] = 0
+    return r
+
+
+def make(n, level, meta, agents, recipes, scheme, max_steps=30, **kw):
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    args = dict(action_scheme=scheme, num_layouts=8, auto_reset=True)
+    args.update(kw)
+    return CookingVecEnv(n, level, meta, agents, max_steps, recipes, **args)
+
+
+CASES = [
+    ("scheme3", "coop_test", 2, ["TomatoLettuceSalad", "CarrotBanana"], "example"),
+    ("scheme1", "switch_test", 2, ["MashedCarrotBanana", "TomatoSalad"], "example"),
+    ("scheme3", "crowded_6x5", 4, ["TomatoSalad", "TomatoLettuceSalad", "no_recipe", "MashedCarrotBanana"], "crowded_6x5"),
+    ("scheme3", "large_16x16", 4, ["TomatoLettuceSalad", "CarrotBanana", "AppleWatermelon", "CucumberOnion"], "large_16x16"),
+    ("scheme1", "large_16x16", 2, ["TomatoLettuceOnionSalad", "MashedCarrotBanana"], "large_16x16"),
+    ("scheme3", "huge_20x20", 2, ["TomatoLettuceSalad", "CarrotBanana"], "huge_20x20"),
+]
+
+
+def ring_run(env, ring, runs, fused):
+    """issues the runs [(K, first_slot), ...] over the ring [period, n, A]; returns (outputs after every run, state, stats)"""
+    period, n, A = ring.shape
+    d_ring = env.alloc((period, n, A), np.int32); d_ring.from_host(ring)
+    d_obs, d_rew = env.alloc((n, A, env.F), np.float64), env.alloc((n, A), np.float64)
+    d_t, d_u = env.alloc((n, A), np.uint8), env.alloc((n, A), np.uint8)
+    env.set_ring_fused(fused)
+    env.ring_fused_steps(reset=True)
+    outs = []
+    for K, first in runs:
+        env.step_device_ring(K, d_ring, n * A, period, first, d_obs, d_rew, d_t, d_u)
+        env.sync()
+        outs.append((d_obs.to_host(), d_rew.to_host(), d_t.to_host(), d_u.to_host()))
+    issued = env.ring_fused_steps()
+    for b in (d_ring, d_obs, d_rew, d_t, d_u):
+        b.free()
+    return outs, strip(env.get_state()), env.stats(), issued
+
+
+@pytest.mark.parametrize("scheme,level,agents,recipes,meta", CASES)
+def test_ring_fused_matches_oracle_and_one_launch_per_step(scheme, level, agents, recipes, meta):
+    from oracle_binding import VecOracle
+    n, period = 72, 11
+    runs = [(9, 0), (25, 9), (2, 1), (40, 3)]                     # wraps the ring several times, starts in the middle of it
+    rng = np.random.default_rng(5)
+    res = {}
+    for fused in (True, False):
+        try:
+            env = make(n, level, meta, agents, recipes, scheme)
+        except FileNotFoundError:
+            pytest.skip(f"level {level} not shipped")
+        env.reset(return_obs=False)
+        if fused:
+            orc = VecOracle.from_vec_env(env)
+            orc.reset()
+            ring = rng.integers(0, env.n_actions, size=(period, n, agents), dtype=np.int32)
+            ring[rng.random(ring.shape) < 0.03] = -1
+        res[fused] = ring_run(env, ring, runs, fused)
+        if fused:
+            outs, state, stats, issued = res[True]
+            assert issued == sum(K for K, _ in runs)
+            for (K, first), (obs, rew, term, trunc) in zip(runs, outs):
+                for k in range(K):
+                    oo, ro, to, uo = orc.step(ring[(first + k) % period], want_obs=(k == K - 1))
+                assert np.array_equal(bits(obs), bits(oo)) and np.array_equal(bits(rew), bits(ro))
+                assert np.array_equal(term, to) and np.array_equal(trunc, uo)
+            assert np.array_equal(state, orc.records)
+            assert int(env.get_state()[:, soa.W_EPISODE].min()) >= 2      # auto-reset passes happened inside the launches
+        env.close()
+    (of, sf, tf, nf), (oo_, so, to_, no) = res[True], res[False]
+    assert no == 0
+    assert np.array_equal(sf, so) and tf == to_
+    for a, b in zip(of, oo_):
+        assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+
+
+def test_ring_fused_with_despawn_respawn():
+    """the keyed spawn stream does not depend on how the steps are launched"""
+    res = []
+    for fused in (True, False):
+        env = make(96, "crowded_6x5", "crowded_6x5", 4, ["TomatoSalad", "TomatoLettuceSalad", "no_recipe", "MashedCarrotBanana"], "scheme3",
+                   max_steps=40, agent_despawn_rate=0.05, agent_respawn_rate=0.2, grace_period=3, spawn_seed=9)
+        env.reset(return_obs=False)
+        ring = np.random.default_rng(2).integers(0, env.n_actions, size=(16, 96, 4), dtype=np.int32)
+        res.append(ring_run(env, ring, [(50, 0), (33, 2)], fused))
+        env.close()
+    (of, sf, tf, nf), (oo, so, to, no) = res
+    assert nf == 83 and no == 0
+    assert np.array_equal(sf, so) and tf == to
+    for a, b in zip(of, oo):
+        assert all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(a, b))
+
+
+def test_ring_fused_falls_back():
+    """other strides and a compact output are issued as before (and give the same results)"""
+    n, A, period = 64, 2, 8
+    env = make(n, "coop_test", "example", A, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3")
+    env.reset(return_obs=False)
+    env.set_ring_fused(True)
+    ring = np.zeros((period, n + 4, A), np.int32)                 # padded slots: stride != n * A
+    ring[:, :n] = np.random.default_rng(3).integers(0, 5, size=(period, n, A), dtype=np.int32)
+    d_ring = env.alloc(ring.shape, np.int32); d_ring.from_host(ring)
+    d_obs, d_rew = env.alloc((n, A, env.F), np.float64), env.alloc((n, A), np.float64)
+    d_t, d_u = env.alloc((n, A), np.uint8), env.alloc((n, A), np.uint8)
+    env.step_device_ring(12, d_ring, (n + 4) * A, period, 0, d_obs, d_rew, d_t, d_u)
+    env.sync()
+    assert env.ring_fused_steps() == 0
+    d_codes = env.alloc((n, A, env.codes_pitch), np.uint8)
+    env.set_compact_output(d_codes)
+    dense = env.alloc((period, n, A), np.int32); dense.from_host(np.ascontiguousarray(ring[:, :n]))
+    env.step_device_ring(12, dense, n * A, period, 0, d_obs, d_rew, d_t, d_u)
+    env.sync()
+    assert env.ring_fused_steps() == 0
+    assert np.array_equal(env.obs_table()[d_codes.to_host()[:, :, :env.F]].view(np.uint64), bits(d_obs.to_host()))
+    env.set_compact_output(None)
+    env.step_device_ring(12, dense, n * A, period, 0, d_obs, d_rew, d_t, d_u)
+    env.sync()
+    assert env.ring_fused_steps() == 12
+    env.close()
+
+
+def test_ring_fused_config2_full_size():
+    """BASELINE config 2 (4096 envs) through fused ring runs against one launch per step"""
+    n, A, period = 4096, 2, 64
+    res = []
+    for fused in (True, False):
+        env = make(n, "coop_test", "example", A, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3", max_steps=400, num_layouts=256)
+        env.reset(return_obs=False)
+        ring = np.random.default_rng(0).integers(0, 5, size=(period, n, A), dtype=np.int32)
+        res.append(ring_run(env, ring, [(500, 0), (77, 52)], fused))
+        env.close()
+    (of, sf, tf, nf), (oo, so, to, no) = res
+    assert nf == 577 and np.array_equal(sf, so) and tf == to
+    for a, b in zip(of, oo):
+        assert all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(a, b))

@@ -105,7 +105,7 @@ def test_c_abi_exports_every_declared_symbol(repo_root):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in cookingzoo.h but not exported"
     assert declared == {n for n, _, _ in _native.SYMBOLS}, "ctypes binding and header disagree"
-    assert _native.lib().cz_abi_version() == 5
+    assert _native.lib().cz_abi_version() == 6
 
 
 def test_struct_layouts_match_header():
