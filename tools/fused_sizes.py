@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Fused rollouts by batch size (bench workload, 32 steps per launch): on-device actions with a float64 trajectory (cz_rollout),
-and with a compact trajectory (cz_rollout_compact).  env-steps/s and ns per env-step.
+with a compact trajectory (cz_rollout_compact), and ring runs fused with the float64 rows
+written in place (cz_set_ring_fused).  env-steps/s and ns per env-step.
     python3 tools/fused_sizes.py [N ...]"""
 import os, sys, time
 import numpy as np
@@ -34,6 +35,21 @@ for N in sizes:
             best = min(best, (time.perf_counter() - t0) / (reps * T))
         out.append(best)
         buf.free()
+    # ring runs fused, outputs in place (cz_set_ring_fused): 64-slot ring, runs of 512 steps
+    period = 64
+    d_ring = env.alloc((period, N, 2), np.int32)
+    d_ring.from_host(np.random.default_rng(1).integers(0, 5, size=(period, N, 2), dtype=np.int32))
+    o = (env.alloc((N, 2, env.F), np.float64), env.alloc((N, 2), np.float64), env.alloc((N, 2), np.uint8), env.alloc((N, 2), np.uint8))
+    env.set_ring_fused(True)
+    K = 512
+    env.step_device_ring(K, d_ring, N * 2, period, 0, *o); env.sync()
+    best = 1e9
+    for rep in range(3):
+        t0 = time.perf_counter()
+        env.step_device_ring(K, d_ring, N * 2, period, 0, *o)
+        env.sync()
+        best = min(best, (time.perf_counter() - t0) / K)
+    out.append(best)
     f = lambda b: "n/a" if b is None else "%7.2f us per step = %5.2f G env-steps/s (%.3f ns per env-step)" % (b * 1e6, N / b / 1e9, b * 1e9 / N)
-    print("N=%6d  float64 trajectory: %s   compact trajectory: %s" % (N, f(out[0]), f(out[1])))
+    print("N=%6d  float64 trajectory: %s   compact trajectory: %s   ring run fused, float64 rows in place: %s" % (N, f(out[0]), f(out[1]), f(out[2])))
     env.close()
