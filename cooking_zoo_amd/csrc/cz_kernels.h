@@ -282,7 +282,7 @@ __device__ __forceinline__ uint4_t load_desc4(const Params &P, uint32_t layout, 
     const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(P.lay_desc), 0, P.L * P.F * 4, 0x00020000);
     return __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(rd, f * 4u, layout * (uint32_t)P.F * 4u, 0));
 }
-template <int OPL, int CPL, int NA>
+template <int OPL, int CPL, int NA, bool F64 = true>
 __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, Lds<CPL> &s,
                                         const double *lut, uint32_t (&dsc)[OBS_CHUNK], uint32_t submask, double *__restrict__ out /* [A][F] of this env */,
                                         bool objs_changed = true, bool cells_changed = true, uint8_t *__restrict__ codes = nullptr /* [A][Fp] */,
@@ -378,7 +378,7 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
             }
         }
     }
-    if (!out) { __builtin_amdgcn_wave_barrier(); return; }
+    if (!F64 || !out) { __builtin_amdgcn_wave_barrier(); return; }      // (F64 = false: the codes-only instance carries no float64 path)
     decltype(__builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0)) rs[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) rs[a] = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)a * (uint32_t)P.F, 0, P.F * 8, 0x00020000);
@@ -625,7 +625,8 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
 // carries none of it: as a run-time branch it cost the random-action rollout 4 %).  FUSED = 3: one step that also (or only)
 // writes the compact observation (cz_step_device_compact / cz_set_compact_output; its own instance as well: compiled into the
 // ordinary one-step kernel the path cost every launch 0.2 us, register allocation and a longer prologue, even when unused).
-// FUSED = 4: P.T steps over the on-device action stream with a compact trajectory [t][env][agent][pitch] (cz_rollout_compact).
+// FUSED = 4: P.T steps over the on-device action stream with a compact trajectory [t][env][agent][pitch] (cz_rollout_compact);
+// FUSED = 5: the same without a float64 trajectory beside it (codes only).
 // What the very first loads of a wave need travels as leading scalar kernel arguments: the build preloads them into
 // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, gfx940+), so the record / action / table loads are issued
 // without waiting for an argument fetch; everything else stays in the by-value block `P0`, fetched meanwhile.
@@ -688,7 +689,12 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     double *retp = reinterpret_cast<double *>(rec + RET_WORD0);
     // ---- an overlapped launch first waits for its env's predecessor (SEQ_* in cz_device.h); ordinary launches skip this
     uint32_t *const seqw = P.state + (size_t)P.N * P.RW + (size_t)env * SEQ_STRIDE_WORDS;
-    constexpr bool FUSED = FUSED_MODE == 1 || FUSED_MODE == 2 || FUSED_MODE == 4, EXT = FUSED_MODE == 2, CODES = FUSED_MODE == 3 || FUSED_MODE == 4;
+    constexpr bool FUSED = FUSED_MODE == 1 || FUSED_MODE == 2 || FUSED_MODE == 4 || FUSED_MODE == 5, EXT = FUSED_MODE == 2;
+    constexpr bool CODES = FUSED_MODE == 3 || FUSED_MODE == 4 || FUSED_MODE == 5;
+    // mode 5: a fused rollout that writes codes ONLY (cz_rollout_compact without a float64 trajectory).  Without the float64 path -
+    // its six descriptor registers, its encode - the codes' own descriptor words fit the registers for the whole launch (mode 4 reloads
+    // them every step: held there they cost 136 vector registers, three waves per SIMD)
+    constexpr bool CODES_ONLY = FUSED_MODE == 5;
     static_assert(!(FUSED && CHAIN), "overlapped launches are one-step launches");
     constexpr bool chained = CHAIN;
     bool abandoned = false;
@@ -747,7 +753,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     if (!CHAIN) init_lds<CPL>(P, cx, lds);
     uint32_t rowv = load_recipe_rows(P, e.recipes, lane);
     uint32_t dsc[OBS_CHUNK];
-    if (P.obs) load_desc(P, e.layout, 0, lane, dsc);
+    if (!CODES_ONLY && P.obs) load_desc(P, e.layout, 0, lane, dsc);
     if (!SUBMASK_EARLY) submask = load_submask(P, lane);
     const int64_t env_global = P.env_id_base + env;
     bool cells_dirty = false, objs_dirty = false, header_dirty = FUSED;
@@ -762,7 +768,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     // on a late argument in front of the prologue's loads costs every launch 0.4 us - and hidden by the dynamics
     CodesPrefetch cpre;
     cpre.layout = e.layout;
-    if (CODES && !FUSED) {
+    if (CODES && (!FUSED || CODES_ONLY)) {
 #pragma unroll
         for (int r = 0; r < CODES_PREFETCH; ++r) cpre.d[r] = load_desc4(P, e.layout, 256u * r + 4u * (uint32_t)lane);
     }
@@ -794,7 +800,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         } else {
             Pt = P;
         }
-        if (CODES && FUSED) {
+        if (CODES && FUSED && !CODES_ONLY) {
             // (a fused rollout fetches the code descriptors again at the top of every step - hidden by the step's dynamics - instead
             // of holding eight more registers across the loop: with them the kernel no longer fits four waves per SIMD)
             cpre.layout = e.layout;
@@ -885,8 +891,8 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         if (Pt.obs || CODES) {
             // (env row x row length: a 32 x 32 -> 64-bit product, two scalar multiplies)
             uint8_t *const codes = CODES ? Pt.codes + (uint64_t)(uint32_t)row * (uint64_t)(uint32_t)(NA * codes_pitch(Pt.F)) : nullptr;
-            double *const obs_row = Pt.obs ? Pt.obs + (uint64_t)(uint32_t)row * (uint64_t)(uint32_t)(NA * Pt.F) : nullptr;
-            observe(Pt, e, cx, lds, lut, dsc, submask, obs_row, img_objs, img_cells, codes, CODES ? &cpre : nullptr);
+            double *const obs_row = !CODES_ONLY && Pt.obs ? Pt.obs + (uint64_t)(uint32_t)row * (uint64_t)(uint32_t)(NA * Pt.F) : nullptr;
+            observe<OPL, CPL, NA, !CODES_ONLY>(Pt, e, cx, lds, lut, dsc, submask, obs_row, img_objs, img_cells, codes, CODES ? &cpre : nullptr);
             img_objs = false; img_cells = false;
         }
         if (o.finished) {                      // (the state is still that of the finished episode: the reset is the next pass)
@@ -1070,6 +1076,9 @@ struct Inst {
         if (fused && P.actions) {
             if (P.scheme == 3) CZ_LAUNCH_STEP(3, 2);
             else CZ_LAUNCH_STEP(1, 2);
+        } else if (fused && P.codes && !P.obs) {
+            if (P.scheme == 3) CZ_LAUNCH_STEP(3, 5);
+            else CZ_LAUNCH_STEP(1, 5);
         } else if (fused && P.codes) {
             if (P.scheme == 3) CZ_LAUNCH_STEP(3, 4);
             else CZ_LAUNCH_STEP(1, 4);
