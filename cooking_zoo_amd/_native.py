@@ -11,6 +11,16 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CZ_LIB", os.path.join(_HERE, "csrc", "libcookingzoo_hip.so"))   # CZ_LIB: diagnostic builds
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cookingzoo.h")
+
+
+def header_abi_version() -> int:
+    """CZ_ABI_VERSION of include/cookingzoo.h - the only place the number is written down."""
+    import re
+    m = re.search(r"^#define\s+CZ_ABI_VERSION\s+(\d+)", open(HEADER_PATH).read(), flags=re.M)
+    if not m:
+        raise RuntimeError(f"no CZ_ABI_VERSION in {HEADER_PATH}")
+    return int(m.group(1))
 
 
 class CzConfig(C.Structure):
@@ -163,6 +173,10 @@ def lib():
                               f"or `make -C cooking_zoo_amd/csrc` (hipcc --offload-arch=gfx950). "
                               f"cooking_zoo_amd has no CPU fallback.")
         L = C.CDLL(LIB_PATH)
+        L.cz_abi_version.restype = _I32
+        if L.cz_abi_version() != header_abi_version():
+            raise NativeError(f"{LIB_PATH} reports ABI {L.cz_abi_version()}, include/cookingzoo.h declares "
+                              f"{header_abi_version()}: rebuild it (make -C cooking_zoo_amd/csrc)")
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)
             fn.restype = res

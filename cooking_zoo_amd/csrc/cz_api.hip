@@ -284,7 +284,7 @@ static int chain_recover(cz_handle h) {
     *(volatile uint32_t *)h->h_chain_err = 0;
     return 0;
 }
-extern "C" int32_t cz_abi_version(void) { return 6; }
+extern "C" int32_t cz_abi_version(void) { return CZ_ABI_VERSION; }
 // diagnostic builds only (tools/phase_profile.py): where the kernels write their s_memtime stamps
 extern "C" int cz_debug_set_stamps(cz_handle h, void *d_buf) {
     if (!h) return 1;

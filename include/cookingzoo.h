@@ -29,6 +29,10 @@
 extern "C" {
 #endif
 
+/* The one place the ABI number lives: cz_abi_version() returns it, cooking_zoo_amd/_native.py parses it from this file
+ * and refuses a library that reports another one, __graft_entry__.build() and the tests compare against it. */
+#define CZ_ABI_VERSION 7
+
 typedef struct cz_handle_s *cz_handle;
 
 /* Batch configuration.  Mirrors the kwargs of CookingEnvironment.__init__ (cooking_env.py:62-64) that

@@ -105,7 +105,7 @@ def test_c_abi_exports_every_declared_symbol(repo_root):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in cookingzoo.h but not exported"
     assert declared == {n for n, _, _ in _native.SYMBOLS}, "ctypes binding and header disagree"
-    assert _native.lib().cz_abi_version() == 6
+    assert _native.lib().cz_abi_version() == _native.header_abi_version() >= 7
 
 
 def test_struct_layouts_match_header():
@@ -179,3 +179,28 @@ def test_late_torch_guard_refuses_the_load_not_the_probe(tmp_path):
             spec.loader.exec_module(None)
     finally:
         sys.path.remove(str(fake))
+
+
+def test_graft_entry_build_succeeds(repo_root):
+    """The driver's build step: `make` of the HIP library (hipcc cross-compiles gfx950 without a GPU) and of the C oracle,
+    then the ABI self-check.  Run in a child so that a stale library already loaded here cannot mask a failure."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); print('BUILD-OK')"],
+                         cwd=repo_root, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "BUILD-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_stale_library_is_refused(repo_root, tmp_path):
+    """A library whose cz_abi_version() differs from include/cookingzoo.h is refused at load."""
+    import subprocess
+    import sys
+    src = tmp_path / "stale.c"
+    src.write_text("int cz_abi_version(void) { return 1; }\n")
+    so = tmp_path / "libstale.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    code = ("import os, sys; os.environ['CZ_LIB'] = %r; sys.path.insert(0, %r)\n"
+            "from cooking_zoo_amd import _native\n"
+            "try:\n    _native.lib()\nexcept _native.NativeError as e:\n    print('REFUSED', e); sys.exit(0)\nsys.exit(3)") % (str(so), repo_root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and "REFUSED" in out.stdout and "ABI 1" in out.stdout, out.stdout + out.stderr
