@@ -126,30 +126,21 @@ class SpawnView:
         return self.active | self.changed
 
 
-class CookingVecEnv:
+class BatchTables:
+    """Everything of a batch that is prepared on the host and never touches the device: meta file, levels, recipe tables and
+    per-env recipe ids, the layout pool (one contiguous slice per level), dims, per-env level, spawn areas.  A `CookingVecEnv`
+    is one of these plus a device handle; `ShardedVecEnv` makes one for the whole batch and hands every device a `shard` of
+    it (same pool and tables, a contiguous range of global env ids), so that nothing is drawn or parsed twice."""
+
     def __init__(self, num_envs, level, meta_file, num_agents, max_steps, recipes, end_condition_all_dishes=False,
                  action_scheme="scheme1", reward_scheme=None, *, num_layouts=256, layout_seed=0, layouts=None,
-                 auto_reset=True, device_id=0, env_id_base=0, max_dyn=None, pinned_outputs=False,
-                 agent_respawn_rate=0.0, grace_period=20, agent_despawn_rate=0.0, spawn_seed=0):
-        """`level` may be one level name/path or a list (env e uses levels[e % len]); `recipes` is a list of
-        names (every env the same) or an int array [num_envs, R] of indices into the recipe book.
-        `layouts` (optional) supplies pre-instantiated Layout objects per level instead of drawing
-        `num_layouts` of them with random.Random(layout_seed).
-        `pinned_outputs=True`: `step` / `reset` / `observe` return views of page-locked host buffers owned by the env
-        (overwritten by the next call) instead of fresh arrays -- the copy engines then write them directly, which is what
-        a host-array step of thousands of envs spends its time on (18 MB of observations per step at 4096 envs).
-        `agent_despawn_rate` / `agent_respawn_rate` / `grace_period`: agent despawn / respawn (cooking_world.py:267-290)
-        for every world of the batch, evaluated by the step kernels themselves with keyed random streams (cz_set_spawn) -
-        on every stepping path (`step`, `step_device`, `step_device_ring`, `rollout`).  `self.spawn` is a read-only view of
-        that bookkeeping (`active`, `grace`, and after a host-array `step` also `changed`)."""
-        self._pinned = bool(pinned_outputs)
-        self._pin_bufs = {}
+                 env_id_base=0, max_dyn=None, agent_respawn_rate=0.0, grace_period=20, agent_despawn_rate=0.0, spawn_seed=0):
         self._spawn_cfg = (float(agent_despawn_rate), float(agent_respawn_rate), int(grace_period), int(spawn_seed))
-        self.spawn = None
         if action_scheme not in ACTION_SCHEMES:
             raise ValueError("action_scheme must be 'scheme1' or 'scheme3' (scheme2 raises AttributeError in the "
                              "reference: action_scheme2.py:15)")
         self.num_envs, self.num_agents, self.max_steps = int(num_envs), int(num_agents), int(max_steps)
+        self.env_id_base = int(env_id_base)
         self.action_scheme = action_scheme
         self.scheme_class = ACTION_SCHEMES[action_scheme]
         self.n_actions = len(self.scheme_class.ACTIONS)
@@ -198,30 +189,9 @@ class CookingVecEnv:
         D = max_dyn if max_dyn is not None else max(max(_ll.level_max_dyn(lv) for lv in self.level_objects),
                                                     max(l.slots_used for l in self.layouts))
         self.dims = soa.Dims(W, H, max(1, D), self.num_agents, self.F)
-
-        # ---- device handle
-        L = _native.lib()
-        rs = self.reward_scheme
-        self._cfg = _native.CzConfig(self.num_envs, self.num_agents, W, H, self.dims.D, self.F, self.scheme_class.CODE,
-                                     self.max_steps, int(self.end_condition_all_dishes), self.num_recipes,
-                                     int(bool(auto_reset)), int(device_id), int(env_id_base),
-                                     float(rs["recipe_reward"]), float(rs["max_time_penalty"]),
-                                     float(rs["recipe_penalty"]), float(rs["recipe_node_reward"]))
-        h = C.c_void_p()
-        rc = L.cz_create(C.byref(self._cfg), C.byref(h))
-        if rc != 0:
-            raise _native.NativeError((L.cz_last_error(None) or b"cz_create failed").decode())
-        self._h = h
-        self.env_id_base = int(env_id_base)
-        assert L.cz_record_words(self._h) == self.dims.RW
-        _native.check(self._h, L.cz_load_recipes(self._h, _ptr(self.recipe_table), len(self.book_names), self.recipe_nodes))
-        self._upload_layouts()
-        self._buffers = []
-        self.env_level = np.arange(self.num_envs) % len(self.levels)
-        self._steps = 0                       # env steps issued so far (every stepping method counts)
-        self._lay_groups, self._lay_active = 1, 0
-        self._rot = None                      # rotate_layouts state
-        self.rotation_events = []             # (step index, "group", groups, active) / (step index, "layouts", first slot, [Layout])
+        # env e of the whole (unsharded) batch plays level e % len(levels): keyed by the GLOBAL id, so a shard sees its own part
+        self.env_level = (self.env_id_base + np.arange(self.num_envs)) % len(self.levels)
+        self.spawn_cells = self.level_of_layout = None
         if self._spawn_cfg[0] or self._spawn_cfg[1]:
             # spawn areas per level (parsing.py:118-151: the AGENTS entries of the level file, one per agent up to MAX_COUNT each)
             self.spawn_cells = []                                        # [level][agent] -> (x candidates, y candidates)
@@ -231,6 +201,75 @@ class CookingVecEnv:
             self.level_of_layout = np.zeros(len(self.layouts), dtype=np.uint8)
             for li, (base, count) in enumerate(self.pool_slices):
                 self.level_of_layout[base:base + count] = li
+
+    def shard(self, begin, count):
+        """The tables of envs [begin, begin + count) of this batch: the same pool, recipes and spawn areas (shared, not
+        copied), global ids env_id_base + begin ..."""
+        import copy
+        if not (0 <= begin and begin + count <= self.num_envs and count > 0):
+            raise ValueError(f"shard [{begin}, {begin + count}) outside the batch of {self.num_envs} envs")
+        t = copy.copy(self)
+        t.num_envs, t.env_id_base = int(count), self.env_id_base + int(begin)
+        t.recipe_ids = np.ascontiguousarray(self.recipe_ids[begin:begin + count])
+        t.env_level = self.env_level[begin:begin + count]
+        t.layouts = list(self.layouts)            # (every handle keeps its own record of what its pool holds after updates)
+        return t
+
+
+class CookingVecEnv:
+    def __init__(self, num_envs, level=None, meta_file=None, num_agents=None, max_steps=None, recipes=None,
+                 end_condition_all_dishes=False, action_scheme="scheme1", reward_scheme=None, *, num_layouts=256,
+                 layout_seed=0, layouts=None, auto_reset=True, device_id=0, env_id_base=0, max_dyn=None, pinned_outputs=False,
+                 agent_respawn_rate=0.0, grace_period=20, agent_despawn_rate=0.0, spawn_seed=0, tables=None):
+        """`level` may be one level name/path or a list (env e uses levels[e % len], e the global id); `recipes` is a list of
+        names (every env the same) or an int array [num_envs, R] of indices into the recipe book.
+        `layouts` (optional) supplies pre-instantiated Layout objects per level instead of drawing
+        `num_layouts` of them with random.Random(layout_seed).
+        `pinned_outputs=True`: `step` / `reset` / `observe` return views of page-locked host buffers owned by the env
+        (overwritten by the next call) instead of fresh arrays -- the copy engines then write them directly, which is what
+        a host-array step of thousands of envs spends its time on (18 MB of observations per step at 4096 envs).
+        `agent_despawn_rate` / `agent_respawn_rate` / `grace_period`: agent despawn / respawn (cooking_world.py:267-290)
+        for every world of the batch, evaluated by the step kernels themselves with keyed random streams (cz_set_spawn) -
+        on every stepping path (`step`, `step_device`, `step_device_ring`, `rollout`).  `self.spawn` is a read-only view of
+        that bookkeeping (`active`, `grace`, and after a host-array `step` also `changed`).
+        `tables`: a prepared `BatchTables` (then the configuration arguments before `auto_reset` are ignored)."""
+        self._pinned = bool(pinned_outputs)
+        self._pin_bufs = {}
+        self.spawn = None
+        if tables is None:
+            tables = BatchTables(num_envs, level, meta_file, num_agents, max_steps, recipes, end_condition_all_dishes,
+                                 action_scheme, reward_scheme, num_layouts=num_layouts, layout_seed=layout_seed,
+                                 layouts=layouts, env_id_base=env_id_base, max_dyn=max_dyn,
+                                 agent_respawn_rate=agent_respawn_rate, grace_period=grace_period,
+                                 agent_despawn_rate=agent_despawn_rate, spawn_seed=spawn_seed)
+        self.tables = tables
+        for k, v in vars(tables).items():           # the env reads (and, for the layout pool, edits) its own copies of the names
+            setattr(self, k, v)
+        W, H = self.dims.W, self.dims.H
+
+        # ---- device handle
+        L = _native.lib()
+        rs = self.reward_scheme
+        self._cfg = _native.CzConfig(self.num_envs, self.num_agents, W, H, self.dims.D, self.F, self.scheme_class.CODE,
+                                     self.max_steps, int(self.end_condition_all_dishes), self.num_recipes,
+                                     int(bool(auto_reset)), int(device_id), int(self.env_id_base),
+                                     float(rs["recipe_reward"]), float(rs["max_time_penalty"]),
+                                     float(rs["recipe_penalty"]), float(rs["recipe_node_reward"]))
+        h = C.c_void_p()
+        rc = L.cz_create(C.byref(self._cfg), C.byref(h))
+        if rc != 0:
+            raise _native.NativeError((L.cz_last_error(None) or b"cz_create failed").decode())
+        self._h = h
+        self.device_id = int(device_id)
+        assert L.cz_record_words(self._h) == self.dims.RW
+        _native.check(self._h, L.cz_load_recipes(self._h, _ptr(self.recipe_table), len(self.book_names), self.recipe_nodes))
+        self._upload_layouts()
+        self._buffers = []
+        self._steps = 0                       # env steps issued so far (every stepping method counts)
+        self._lay_groups, self._lay_active = 1, 0
+        self._rot = None                      # rotate_layouts state
+        self.rotation_events = []             # (step index, "group", groups, active) / (step index, "layouts", first slot, [Layout])
+        if self.spawn_cells is not None:
             self._set_spawn()
             self.spawn = SpawnView(self)
 
@@ -267,6 +306,9 @@ class CookingVecEnv:
 
     def set_layouts(self, layouts):
         """Replace the whole pool (single-level batches; used by the single-env facade at reset)."""
+        if self.spawn is not None and len(self.levels) > 1:
+            raise ValueError("set_layouts replaces the pool of a single-level batch; a multi-level batch with despawn / respawn "
+                             "would lose its layout -> level map (use update_layouts, which keeps every slot's level)")
         self.layouts = list(layouts)
         self.pool_slices = [(0, len(self.layouts))]
         self._upload_layouts()

@@ -198,9 +198,10 @@ class VecOracle:
 
     @classmethod
     def from_vec_env(cls, env, num_envs=None, env_id_base=None, auto_reset=1):
+        """env: a CookingVecEnv or its device-free half, a cooking_zoo_amd.vec_env.BatchTables"""
         n = env.num_envs if num_envs is None else num_envs
         me = cls._from_vec_env(env, n, env_id_base, auto_reset)
-        if getattr(env, "spawn", None) is not None:              # the batch evaluates despawn / respawn on the device: so does its twin
+        if getattr(env, "spawn_cells", None) is not None:        # the batch evaluates despawn / respawn on the device: so does its twin
             d, r, g, seed = env._spawn_cfg
             me.oracle.set_spawn(d, r, g, seed, env.spawn_cells, env.level_of_layout)
         return me

@@ -3,6 +3,13 @@ assignment / horizon / reward scheme / end condition per case, and (round 4) des
 wide tables, a layout pool that is switched and refreshed mid-run; a fused rollout of T steps over the counter-based action
 stream, then final records, last observation and statistics must agree bit for bit.
 
+Round 5: every case is also run under a BIASED action source (tests/fuzz_policy.py: walk to a cell that holds an object or is
+an action object and use it; scheme1 draws EXECUTE / PICK_UP_SPECIAL with raised probability) computed from the oracle's
+records, fed to the device through cz_rollout_actions and the one-step paths - uniform random actions hardly ever plate a
+dish, absorb from a counter, deliver or complete a recipe.  Which transitions a run exercised is counted from the oracle's
+record diffs; the last test of the module prints the table and asserts that nothing stayed at zero (all events in a soak,
+the common ones in the default handful).
+
 Default: a handful of cases (seconds).  CZ_FUZZ_CASES=N widens it for one-off soak runs (200 cases are about
 37 M env-steps)."""
 import os
@@ -172,3 +179,100 @@ def run_case(i, kw, seed, extra):
     st = env.stats()
     assert st["episodes"] == int(orc.records[:, soa.W_EPISODE].sum()) + int((orc.records[:, soa.W_STATUS] & 1).sum()), ctx
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the same configurations under the biased action source, with event accounting
+# ---------------------------------------------------------------------------------------------------------------------------
+from fuzz_policy import EVENTS, BumperActions, EventCounter   # noqa: E402
+
+EVENT_TOTALS = {k: 0 for k in EVENTS}
+EVENT_STEPS = [0, 0]                      # live env-steps, cases
+# the default handful must reach these; a soak (>= 200 cases) must reach every event of fuzz_policy.EVENTS
+CORE_EVENTS = ["pick_up", "put_down", "chop", "plate_add", "static_accepts", "delivery", "marks_changed", "truncation"]
+
+
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_biased_actions_match_oracle(i):
+    kw, seed, extra = draw_case(i)
+    if extra["wide"]:
+        from cooking_zoo_amd.cooking_book import recipe_drawer as rd
+        from test_custom_recipes import register_fixture_recipes
+        assert not rd.RECIPE_STORE
+        register_fixture_recipes()
+    try:
+        run_biased_case(i, kw, seed)
+    finally:
+        if extra["wide"]:
+            rd.RECIPE_STORE.clear()
+
+
+def run_biased_case(i, kw, seed):
+    n, chunk, n_chunks, singles = 256, 96, 3, 48
+    if kw["level"].startswith(("huge", "limit", "dense")):  # (the policy's distance maps over 1024 cells are the slow part, on the host)
+        n = 96
+    kw = dict(kw)
+    kw["max_steps"] = max(kw["max_steps"], 60)              # deep states need a few dozen steps (the uniform half keeps short horizons)
+    env = make(n, **kw)
+    orc = oracle_for(env)
+    env.reset(return_obs=False)
+    orc.reset()
+    A, F = kw["num_agents"], env.F
+    ctx = f"biased case {i}: {kw}"
+    rng = np.random.default_rng(seed ^ 0x5EED)
+    pol = BumperActions(env.dims, env.scheme_class.CODE, rng)
+    ev = EventCounter(env.dims)
+
+    def oracle_steps(T, want_last_obs=True):
+        """T oracle steps under the policy: the actions, every step's rewards / flags, the last observation"""
+        acts = np.empty((T, n, A), np.int32)
+        rew, term, trunc = np.empty((T, n, A)), np.empty((T, n, A), np.uint8), np.empty((T, n, A), np.uint8)
+        obs = None
+        for t in range(T):
+            before = orc.records.copy()
+            acts[t] = pol.act(before)
+            obs, rew[t], term[t], trunc[t] = orc.step(acts[t], want_obs=(t == T - 1) and want_last_obs)
+            pol.observe_result(orc.records)
+            ev.update(before, orc.records, term[t], trunc[t])
+        return acts, obs, rew, term, trunc
+
+    d_act = env.alloc((chunk, n, A), np.int32)
+    d_obs, d_rew = env.alloc((chunk, n, A, F), np.float64), env.alloc((chunk, n, A), np.float64)
+    d_t, d_u = env.alloc((chunk, n, A), np.uint8), env.alloc((chunk, n, A), np.uint8)
+    for c in range(n_chunks):                               # fused steps over the policy's actions (kernel mode 2)
+        acts, oo, ro, to, uo = oracle_steps(chunk)
+        d_act.from_host(acts)
+        env.rollout_actions(d_act, chunk, d_obs, d_rew, d_t, d_u)
+        env.sync()
+        assert np.array_equal(strip(env.get_state()), orc.records), (ctx, "records after chunk", c)
+        assert np.array_equal(bits(d_rew.to_host()), bits(ro)), (ctx, "rewards of chunk", c)
+        assert np.array_equal(d_t.to_host(), to) and np.array_equal(d_u.to_host(), uo), (ctx, "flags of chunk", c)
+        assert np.array_equal(bits(d_obs.to_host()[-1]), bits(oo)), (ctx, "last observation of chunk", c)
+    table = env.obs_table()
+    for t in range(singles):                                # one launch per step (modes 0 and 3), host arrays
+        acts, oo, ro, to, uo = oracle_steps(1)
+        if t % 4 == 3:
+            codes, r, te, tr = env.step_compact(acts[0])
+            o = table[codes[:, :, :F]]
+        else:
+            o, r, te, tr = env.step(acts[0])
+        assert np.array_equal(bits(o), bits(oo)) and np.array_equal(bits(r), bits(ro[0])), (ctx, "single step", t)
+        assert np.array_equal(te, to[0]) and np.array_equal(tr, uo[0]), (ctx, "single step flags", t)
+    assert np.array_equal(strip(env.get_state()), orc.records), ctx
+    for k in EVENTS:
+        EVENT_TOTALS[k] += ev.counts[k]
+    EVENT_STEPS[0] += ev.steps
+    EVENT_STEPS[1] += 1
+    env.close()
+
+
+def test_zz_biased_runs_reached_the_deep_transitions():
+    """(runs last in the module) the event table of the biased runs; nothing that must be reached stayed at zero"""
+    if EVENT_STEPS[1] == 0:
+        pytest.skip("no biased case ran in this session")
+    print(f"\nevent coverage of {EVENT_STEPS[1]} biased cases, {EVENT_STEPS[0]} live env-steps (device == oracle on all of them):")
+    for k in EVENTS:
+        print(f"  {k:20s} {EVENT_TOTALS[k]}")
+    must = EVENTS if EVENT_STEPS[1] >= 200 else (CORE_EVENTS if EVENT_STEPS[1] >= 6 else [])
+    missing = [k for k in must if EVENT_TOTALS[k] == 0]
+    assert not missing, f"never exercised: {missing}"

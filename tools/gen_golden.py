@@ -350,8 +350,58 @@ def level_max_dyn(level_path_or_name):
     return max(n, 1)          # the record always has at least one (possibly unused) slot
 
 
-def capture_episode(cfg, seed, policy_name, max_len=None, recipe_ids=None, recipe_nodes=soa.NARROW_NODES):
-    """Returns dict of arrays for one episode (reset + steps until done / max_len)."""
+class ReferenceCrash(Exception):
+    """Raised by capture_episode(on_crash="raise") - kept for callers that want the old behaviour by name."""
+
+
+def crash_record(exc, step, act):
+    """What diff_fuzz keeps of an exception that left the reference's accumulated_step: type, message, and the frames of
+    the traceback that lie inside the reference (innermost last), as `file:line function`."""
+    import traceback
+    frames = [f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.name}" for fr in traceback.extract_tb(exc.__traceback__)
+              if os.path.abspath(fr.filename).startswith(REFERENCE)]
+    detail = ""
+    tb = exc.__traceback__
+    while tb is not None:                               # the innermost frame's view of what was being used
+        loc = tb.tb_frame.f_locals
+        so = loc.get("static_object")
+        if so is not None:
+            content = getattr(so, "content", [])
+            detail = (f"{type(so).__name__} status={getattr(getattr(so, 'status', None), 'name', None)} content="
+                      + "[" + ",".join(f"{type(o).__name__}({getattr(getattr(o, 'chop_state', None), 'name', '-')}/"
+                                       f"{getattr(getattr(o, 'blend_state', None), 'name', '-')})" for o in content) + "]")
+        tb = tb.tb_next
+    return {"type": type(exc).__name__, "message": str(exc)[:120], "frames": frames, "step": int(step),
+            "action": [int(a) for a in act], "detail": detail}
+
+
+# Reference crash sites the build answers with a defined no-op (DESIGN.md section 2, include/cookingzoo.h "deviations").
+# `tolerant_reference()` turns exactly those raise sites of the reference into that no-op - nothing else - so that the
+# generator can let the REFERENCE compute the rest of the crashing step (other agents, progress_world, rewards,
+# observation): the post-crash expectations of the *_refcrash_* fixtures are reference outputs, not oracle outputs.
+def _tolerant_cutboard_action(orig):
+    def action(self):
+        out = orig(self)
+        # world_objects.py:250-269: READY with empty content, or READY with content whose chop() does not execute,
+        # falls off the loop -> None -> TypeError at cooking_world.py:162.  Build: nothing created / deleted / executed.
+        return ([], [], False) if out is None else out
+    return action
+
+
+class tolerant_reference:
+    def __enter__(self):
+        self._orig = wo.Cutboard.action
+        wo.Cutboard.action = _tolerant_cutboard_action(self._orig)
+        return self
+
+    def __exit__(self, *a):
+        wo.Cutboard.action = self._orig
+        return False
+
+
+def capture_episode(cfg, seed, policy_name, max_len=None, recipe_ids=None, recipe_nodes=soa.NARROW_NODES, on_crash="raise"):
+    """Returns dict of arrays for one episode (reset + steps until done / max_len).  on_crash="record": an exception out
+    of the reference's accumulated_step ends the episode at the last good step; `crash` (crash_record) names it."""
     random.seed(seed)
     np.random.seed(seed)
     rng = np.random.default_rng(seed + 7919)
@@ -392,9 +442,16 @@ def capture_episode(cfg, seed, policy_name, max_len=None, recipe_ids=None, recip
     actions, rewards, terms, truncs = [], [], [], []
     statics = static_lists(env)
     limit = max_len or cfg["max_steps"]
+    crash = None
     for step in range(limit):
         act = [p.act(world, i) for i, p in enumerate(pols)]
-        env.accumulated_step(act)
+        try:
+            env.accumulated_step(act)
+        except Exception as exc:                        # noqa: BLE001 - whatever the reference raises is the finding
+            if on_crash != "record":
+                raise
+            crash = crash_record(exc, step, act)
+            break
         actions.append(act)
         rewards.append([float(env.rewards[a]) for a in env.possible_agents])
         for a in env.possible_agents:
@@ -408,6 +465,7 @@ def capture_episode(cfg, seed, policy_name, max_len=None, recipe_ids=None, recip
         if any(terms[-1]) or any(truncs[-1]):
             break
     return {
+        "crash": crash,
         "dims": np.array(dims.as_tuple(), dtype=np.int32),
         "states": np.stack(states),
         "obs": np.stack(obs),
