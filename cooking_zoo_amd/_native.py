@@ -69,6 +69,8 @@ SYMBOLS = [
     ("cz_get_state", C.c_int, [_VP, _I64, _I64, _VP]),
     ("cz_reset", C.c_int, [_VP, _I64, _I64, _VP, _VP, _VP, _VP]),
     ("cz_observe", C.c_int, [_VP, _I64, _I64, _VP]),
+    ("cz_observe_compact", C.c_int, [_VP, _I64, _I64, _VP]),
+    ("cz_observe_device", C.c_int, [_VP, _I64, _I64, _VP, _VP]),
     ("cz_step", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     ("cz_step_device", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     ("cz_step_device_compact", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
@@ -82,15 +84,12 @@ SYMBOLS = [
     ("cz_step_device_ring", C.c_int, [_VP, _I32, _VP, _I64, _I32, _I32, _VP, _VP, _VP, _VP]),
     ("cz_ring_prepare", C.c_int, [_VP, _I32, _VP, _I64, _I32, _I32, _VP, _VP, _VP, _VP]),
     ("cz_launch_counts", C.c_int, [_VP, C.POINTER(_I64), C.POINTER(_I64), _I32]),
-    ("cz_chain_counts", C.c_int, [_VP, C.POINTER(_I64), _I32]),
-    ("cz_set_overlap", C.c_int, [_VP, _I32]),
     ("cz_set_ring_fused", C.c_int, [_VP, _I32]),
     ("cz_ring_fused_steps", C.c_int64, [_VP, _I32]),
-    ("cz_overlap_limit", _I64, [_VP]),
     ("cz_last_marks", C.c_int, [_VP, _VP]),
     ("cz_set_stream", C.c_int, [_VP, _VP]),
     ("cz_probe_output_only", C.c_int, [_VP, _VP, C.c_size_t, _I32, _VP]),
-    ("cz_probe_occupy", C.c_int, [_VP, _I32, _I32]),
+    ("cz_probe_policy", C.c_int, [_VP, _VP, _VP, _VP]),
     ("cz_probe_closed_loop", C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, C.POINTER(C.c_float)]),
     ("cz_rollout", C.c_int, [_VP, _I32, _U64, _U32, _VP, _VP, _VP, _VP]),
     ("cz_rollout_compact", C.c_int, [_VP, _I32, _U64, _U32, _VP, _VP, _VP, _VP, _VP]),

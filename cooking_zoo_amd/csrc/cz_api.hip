@@ -101,15 +101,6 @@ __global__ __launch_bounds__(64 * ENVS_PER_WG) void k_probe_fill(void *dst, uint
         __builtin_amdgcn_raw_buffer_store_b128(u4{0, 0, 0, 0}, rs, off, 0, 16);
 }
 
-// test aid (cz_probe_occupy): a foreign kernel that does nothing but hold its workgroups' slots - the step kernel's block
-// size and LDS footprint - for `ticks` of the 100 MHz device clock
-__global__ __launch_bounds__(64 * ENVS_PER_WG) void k_probe_occupy(unsigned long long ticks, int *sink) {
-    __shared__ char hold[34 * 1024];
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-    if (sink) sink[0] = hold[threadIdx.x];          // never true: keeps the allocation alive
-}
-
 // measurement aid (cz_probe_closed_loop): the smallest "policy" there is - every agent's next action is a hash of a few
 // doubles of the observation it was just given - so that step k + 1 depends on step k's observation through a kernel of the
 // caller, as in any reinforcement-learning loop
@@ -160,16 +151,6 @@ struct cz_handle_s {
     Params P;
     hipStream_t stream = nullptr;      // the stream every call of this handle is ordered on
     hipStream_t own_stream = nullptr;  // the one cz_create made (cz_set_stream may point `stream` at a caller's)
-    // overlapped ("chained") runs of cz_step_device_ring: odd steps go to aux_stream (SEQ_* in cz_device.h)
-    hipStream_t aux_stream = nullptr;
-    hipStream_t foreign_stream = nullptr;   // cz_probe_occupy only
-    hipEvent_t ev_fork = nullptr;
-    bool chain_enabled = false;        // cz_set_overlap / CZ_CHAIN=1; off: runs are ordered by launch boundaries only (graph replay)
-    int64_t chain_max_envs = 0;        // largest batch that may overlap (half of the envs the device holds at once, see cz_create)
-    uint32_t seq_counter = 0;          // number of the next chained launch (mod 2^30)
-    uint32_t *h_chain_err = nullptr;   // pinned, device-mapped: set by a wave whose hand-off never came
-    int64_t n_chained_kernels = 0;
-    bool chain_wanted_by_env = false;
     Launchers kl;
     int n_layouts = 0, n_recipes = 0;
     uint32_t *d_state = nullptr, *d_lay_init = nullptr, *d_lay_desc = nullptr, *d_recipes = nullptr;
@@ -235,7 +216,7 @@ struct cz_handle_s {
     int64_t tl_count = 0;
     bool graphs_enabled = true;    // CZ_GRAPHS=0: cz_step_device_ring launches everything directly
     bool ring_fused = false;       // cz_set_ring_fused: runs of cz_step_device_ring / _many go out as fused launches (outputs in place)
-    int64_t n_ring_fused_steps = 0;
+    int64_t n_ring_fused_steps = 0, n_ring_fused_launches = 0;
     int32_t ring_prefix = 0;       // CZ_RING_PREFIX: steps of a cz_step_device_ring call launched directly in front of its first graph
     size_t zero_copy_bytes = (size_t)256 << 10;   // cz_step: batches whose buffers fit use the pinned device-mapped block (CZ_ZERO_COPY_BYTES)
     cz_stats *d_gather = nullptr;
@@ -265,25 +246,17 @@ static int fail(cz_handle h, const char *fmt, ...) {
 
 extern "C" const char *cz_last_error(cz_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
 
-// An overlapped launch whose hand-off never came sets the pinned word h_chain_err and leaves; from then on the env states are
-// void and EVERY entry point that launches, synchronises or reads results fails (not only cz_sync), until the caller replaces
-// the whole state (cz_set_state / cz_reset over all envs), which is the documented recovery.
-static int chain_failed(cz_handle h, const char *where) {
-    if (!h->h_chain_err) return 0;
-    const uint32_t w = *(volatile uint32_t *)h->h_chain_err;
-    if (!w) return 0;
-    return fail(h, "%s: an overlapped launch gave up waiting for its predecessor (the envs' states are no longer trustworthy; "
-                   "replace them all with cz_set_state or cz_reset to go on): waited for number %u, last saw ...%u (mod 64), the "
-                   "handle's next number is %u", where, w & 0xFFFFFFu, (w >> 24) & 63u, h->seq_counter);
+// Is the stream this handle's work goes to (a stream of the caller, cz_set_stream) being captured - hipStreamBeginCapture,
+// torch.cuda.graph - right now?  The device-pointer steps (cz_step_device, _compact, _many, _ring, cz_rollout*) are then pure
+// kernel launches: nothing that queries or synchronises (a staged layout update stays staged until the first call outside the
+// capture; no graphs of the library's own inside the caller's), so the capture stays valid and replays do what the launches did.
+static bool caller_capturing(cz_handle h) {
+    if (h->stream == h->own_stream) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
 }
-// all envs have been given a new state: whatever an abandoned run left behind is gone with the old one
-static int chain_recover(cz_handle h) {
-    if (!h->h_chain_err || !*(volatile uint32_t *)h->h_chain_err) return 0;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->aux_stream) HIPCHK(h, hipStreamSynchronize(h->aux_stream));      // every waiting wave has left by now (it saw the word)
-    *(volatile uint32_t *)h->h_chain_err = 0;
-    return 0;
-}
+
 extern "C" int32_t cz_abi_version(void) { return CZ_ABI_VERSION; }
 // diagnostic builds only (tools/phase_profile.py): where the kernels write their s_memtime stamps
 extern "C" int cz_debug_set_stamps(cz_handle h, void *d_buf) {
@@ -382,7 +355,6 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
 #endif
     if (const char *s = getenv("CZ_WT")) h->wt_override = atoi(s);
     if (const char *s = getenv("CZ_GRAPHS")) h->graphs_enabled = atoi(s) != 0;
-    h->chain_wanted_by_env = getenv("CZ_CHAIN") && atoi(getenv("CZ_CHAIN")) != 0;
     if (const char *s = getenv("CZ_RING_PREFIX")) h->ring_prefix = atoi(s) < 0 ? 0 : (atoi(s) > 16 ? 16 : atoi(s));
     if (const char *s = getenv("CZ_ZERO_COPY_BYTES")) h->zero_copy_bytes = (size_t)atoll(s);
 #ifdef CZ_ABLATE
@@ -395,17 +367,6 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     h->kl = (P.D <= 64 && C <= 64) ? launchers_small() : (P.D <= 128 && C <= 256) ? launchers_large() : launchers_huge();
 #endif
     h->huge = P.D > 128 || C > 256;
-    {   // Overlapped launches: a kernel's waves spin until their predecessors, waves of the previous kernel, have run.  A
-        // wave that waits for a workgroup which cannot be dispatched because waiting waves hold the slots it needs would
-        // wait forever, so two of these kernels must fit the device IN FULL, together: N <= half of the envs the device
-        // holds of this kernel (at most two are ever in flight: the third waits for the first on its stream).  A weaker
-        // rule - the waiting kernel alone must not fill the device, 2/3 - timed out at the start of runs on some boxes.
-        hipDeviceProp_t prop;
-        CREATE_CHK(hipGetDeviceProperties(&prop, cfg->device_id));
-        int64_t resident = 0;
-        CREATE_CHK(h->kl.resident_envs(P, prop.multiProcessorCount, &resident));
-        h->chain_max_envs = resident / 2;
-    }
     {   // the reward of a step on which no recipe node changed: cooking_env.py:304-307 with zero deltas, same op order
         double x = 0.0;
         x += (double)0 * P.node_reward;
@@ -415,11 +376,9 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
         P.reward_idle = x;
     }
     const size_t N = (size_t)P.N;
-    // the records, then one sequence word per env, 64 B apart (hand-off of overlapped launches, SEQ_* in cz_device.h)
-    const size_t state_bytes = N * P.RW * 4 + N * SEQ_STRIDE_WORDS * 4;
+    const size_t state_bytes = N * P.RW * 4;
     CREATE_CHK(hipMalloc(&h->d_state, state_bytes));
     CREATE_CHK(hipMemsetAsync(h->d_state, 0, state_bytes, h->stream));
-    // (P.chain_err is set by the first cz_set_overlap(h, 1), together with the second stream)
     CREATE_CHK(hipMalloc(&h->d_stat_u, N * SU_WORDS * 4));
     CREATE_CHK(hipMalloc(&h->d_stat_f, N * SF_WORDS * 8));
     CREATE_CHK(hipMemsetAsync(h->d_stat_u, 0, N * SU_WORDS * 4, h->stream));
@@ -481,7 +440,6 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
         memcpy(h->obs_table, lut, sizeof lut);
     }
 #undef CREATE_CHK
-    if (h->chain_wanted_by_env) (void)cz_set_overlap(h, 1);       // (stays off if another handle of the device has it)
     *out = h;
     return 0;
 }
@@ -490,9 +448,6 @@ extern "C" int cz_destroy(cz_handle h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device_id);
     (void)hipStreamSynchronize(h->stream);
-    if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
-    if (h->foreign_stream) { (void)hipStreamSynchronize(h->foreign_stream); (void)hipStreamDestroy(h->foreign_stream); }
-    if (h->chain_enabled) (void)cz_set_overlap(h, 0);
     if (h->comm && h->rccl) {
         typedef int (*destroy_t)(void *);
         destroy_t f = (destroy_t)dlsym(h->rccl, "ncclCommDestroy");
@@ -512,9 +467,6 @@ extern "C" int cz_destroy(cz_handle h) {
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->h_marks) (void)hipHostFree(h->h_marks);
-    if (h->h_chain_err) (void)hipHostFree(h->h_chain_err);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     for (hipEvent_t e : h->kev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -574,7 +526,6 @@ extern "C" int cz_set_spawn(cz_handle h, double despawn_rate, double respawn_rat
     }
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->aux_stream) HIPCHK(h, hipStreamSynchronize(h->aux_stream));
     if (h->d_spawn_tables) { HIPCHK(h, hipFree(h->d_spawn_tables)); h->d_spawn_tables = nullptr; }
     h->spawn_layouts = 0;
     if (on) {
@@ -614,24 +565,6 @@ extern "C" int32_t cz_record_words(cz_handle h) { return h ? h->P.RW : 0; }
 extern "C" int cz_sync(cz_handle h) {
     if (!h) return fail(nullptr, "null handle");
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->h_chain_err && *(volatile uint32_t *)h->h_chain_err) {
-        if (getenv("CZ_CHAIN_DEBUG")) {          // histogram of the sequence words at the time of the report
-            (void)hipDeviceSynchronize();
-            std::vector<uint32_t> sq((size_t)h->P.N * SEQ_STRIDE_WORDS);
-            (void)hipMemcpy(sq.data(), h->d_state + (size_t)h->P.N * h->P.RW, sq.size() * 4, hipMemcpyDeviceToHost);
-            uint32_t lo = ~0u, hi = 0;
-            for (int e = 0; e < h->P.N; ++e) { lo = sq[(size_t)e * SEQ_STRIDE_WORDS] < lo ? sq[(size_t)e * SEQ_STRIDE_WORDS] : lo; hi = sq[(size_t)e * SEQ_STRIDE_WORDS] > hi ? sq[(size_t)e * SEQ_STRIDE_WORDS] : hi; }
-            fprintf(stderr, "[cz] sequence words: min %u max %u;", lo, hi);
-            for (uint32_t v = lo; v <= hi && v < lo + 8; ++v) {
-                int cnt = 0, first = -1, last = -1;
-                for (int e = 0; e < h->P.N; ++e)
-                    if (sq[(size_t)e * SEQ_STRIDE_WORDS] == v) { ++cnt; if (first < 0) first = e; last = e; }
-                fprintf(stderr, " value %u: %d envs (first %d, last %d);", v, cnt, first, last);
-            }
-            fprintf(stderr, "\n");
-        }
-        return chain_failed(h, "cz_sync");
-    }
     return 0;
 }
 
@@ -777,6 +710,8 @@ extern "C" int cz_load_layouts(cz_handle h, const uint32_t *init_records, const 
     HIPCHK(h, hipMemcpyAsync(h->d_lay_desc, obs_desc, b1, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->n_layouts = n;
+    // (the spawn tables map every layout of the pool to its level: a new pool - even one of the same size - needs cz_set_spawn again)
+    if (h->P.auto_reset & 2) h->spawn_layouts = -1;
     h->lay_groups = 1; h->lay_active = 0; h->upd_ranges.clear(); h->staged_on_copy.clear(); h->staged_on_main.clear(); h->copy_pending = false;
     h->tables_version++;
     h->P.lay_init = h->d_lay_init; h->P.lay_desc = h->d_lay_desc; h->P.L = n;
@@ -833,6 +768,7 @@ extern "C" int cz_update_layouts(cz_handle h, int32_t first, int32_t count, cons
         return fail(h, "cz_update_layouts: slots [%d, %d) outside the resident pool of %d layouts", first, first + count, h ? h->n_layouts : 0);
     if (count > 0 && validate_layouts(h, "cz_update_layouts", init_records, obs_desc, count)) return 1;
     if (set_device(h)) return 1;
+    if (caller_capturing(h)) return fail(h, "cz_update_layouts: not inside a stream capture of the caller (it records an event on the captured stream)");
     const size_t RWb = (size_t)h->P.RW * 4, Fb = (size_t)h->P.F * 4, L = (size_t)h->n_layouts;
     if (!h->copy_stream) {
         HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
@@ -874,6 +810,7 @@ extern "C" int cz_set_layout_group(cz_handle h, int32_t groups, int32_t active) 
     if (groups < 1 || groups > h->n_layouts || active < 0 || active >= groups || h->n_layouts % groups)
         return fail(h, "cz_set_layout_group: need 1 <= groups, 0 <= active < groups, and pool slices that are multiples of groups");
     if (set_device(h)) return 1;
+    if (caller_capturing(h)) return fail(h, "cz_set_layout_group: not inside a stream capture of the caller (it orders copies and waits)");
     if (flush_updates(h, true)) return 1;
     if (h->copy_pending) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copy_done, 0)); h->copy_pending = false; }
     HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->d_lay_block + LC_GROUPS), groups, 1, h->stream));
@@ -909,8 +846,6 @@ extern "C" int cz_set_state(cz_handle h, int64_t b, int64_t c, const uint32_t *r
                 return fail(h, "cz_set_state: record %lld: slot %d is not alive but carries a container tag", (long long)i, s2);
     }
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    if (b == 0 && c == h->P.N) { if (chain_recover(h)) return 1; }
-    else if (chain_failed(h, "cz_set_state")) return 1;
     HIPCHK(h, hipMemcpyAsync(h->d_state + (size_t)b * h->P.RW, records, (size_t)c * h->P.RW * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -923,7 +858,7 @@ extern "C" int cz_get_state(cz_handle h, int64_t b, int64_t c, uint32_t *records
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipMemcpyAsync(records, h->d_state + (size_t)b * h->P.RW, (size_t)c * h->P.RW * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return chain_failed(h, "cz_get_state");
+    return 0;
 }
 
 static int ready(cz_handle h) {
@@ -934,10 +869,9 @@ static int ready(cz_handle h) {
 }
 
 static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr, bool fused = false) {
-    if (chain_failed(h, "step launch")) return 1;
     if ((P.auto_reset & 2) && h->spawn_layouts != h->n_layouts)
-        return fail(h, "despawn / respawn is on, but the layout pool was reloaded with another size (%d -> %d layouts): call cz_set_spawn "
-                       "again (it maps every layout to the level whose spawn areas it uses)", h->spawn_layouts, h->n_layouts);
+        return fail(h, "despawn / respawn is on, but the layout pool was reloaded since cz_set_spawn (now %d layouts): call cz_set_spawn "
+                       "again (it maps every layout to the level whose spawn areas it uses)", h->n_layouts);
     if (!stream) stream = h->stream;
     // write-through observation stores pay when the launch is short enough for the end-of-kernel L2 write-back to be
     // exposed: one step of a moderate batch; streaming stores when one launch's observations do not fit the memory-side
@@ -957,6 +891,7 @@ static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr, boo
     P.timeline = (h->tl_base && h->tl_cap > 0) ? h->tl_base + (size_t)(h->tl_count++ % h->tl_cap) * (size_t)P.N * 2 : nullptr;
 #endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->ktime && caller_capturing(h)) return fail(h, "kernel timing (cz_kernel_time_reset) cannot run inside a stream capture of the caller");
     if (h->ktime) {
         while (h->kev.size() < h->kev_used + 2) {
             hipEvent_t e;
@@ -971,43 +906,6 @@ static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr, boo
     if (h->ktime) HIPCHK(h, hipEventRecord(e1, stream));
     return 0;
 }
-// can this launch be part of an overlapped run?  (one-step kernel with write-through observation stores: two waves of
-// different launches write the same output bytes, so those must not sit dirty in two L2s)
-static bool chainable(cz_handle h, const Params &P) {
-    if (!h->chain_enabled || h->ktime || !P.actions || P.codes || P.N > h->chain_max_envs) return false;      // (no compact output in overlapped runs)
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;   // a caller's capture
-    if (h->wt_override >= 0) return h->wt_override == 1;
-    return (size_t)P.N * P.A * P.F * 8 <= ((size_t)128 << 20);
-}
-// K steps of an overlapped run on the handle's stream and aux_stream alternately; every launch but the first waits per
-// env for its predecessor's sequence number (cz_kernels.h k_step) instead of for the whole previous kernel.
-// * The first and the LAST launch go to the handle's stream.  The first is thereby ordered after whatever the caller queued
-//   before the run, and everything else follows from it env by env.  When the last one has completed, every env has gone
-//   through every step, and a wave publishes its number only after its stores were acknowledged - so later work on the
-//   handle's stream (or a synchronisation of it) needs no join with aux_stream.
-// * aux_stream's kernels would otherwise only spin until the first launch gets to run; if the caller's stream is still busy
-//   that could outlast the spin deadline, so in that case (only) aux_stream first waits for the stream's current tail.
-static int launch_chain(cz_handle h, Params &P, int32_t K, const int32_t *d_ring, int64_t stride, int32_t period, int32_t first_slot) {
-    if (hipStreamQuery(h->stream) != hipSuccess) {
-        (void)hipGetLastError();
-        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
-    }
-    // (hipLaunchKernelGGL costs the host 2.8 us per launch here, against 5.2 us of GPU time; a ready-made argument buffer
-    // through hipModuleLaunchKernel was measured at 3.6 us, tools/enqueue_cost.py)
-    for (int32_t k = 0; k < K; ++k) {
-        P.actions = d_ring + (int64_t)(((int64_t)first_slot + k) % period) * stride;
-        P.seq = SEQ_PUBLISH | (k > 0 ? SEQ_WAIT : 0u) | ((h->seq_counter + (uint32_t)k) & SEQ_MASK);
-        const bool on_main = k == 0 || ((K - 1 - k) & 1) == 0;
-        if (launch_step(h, P, on_main ? h->stream : h->aux_stream)) return 1;
-    }
-    P.seq = 0;
-    h->seq_counter = (h->seq_counter + (uint32_t)K) & SEQ_MASK;
-    h->n_chained_kernels += K;
-    return 0;
-}
-
 extern "C" int cz_reset(cz_handle h, int64_t b, int64_t c, const int32_t *layout_ids, const uint8_t *recipe_ids,
                         const uint32_t *pool_words, double *obs) {
     if (ready(h) || check_range(h, b, c)) return 1;
@@ -1025,8 +923,6 @@ extern "C" int cz_reset(cz_handle h, int64_t b, int64_t c, const int32_t *layout
             pools[(size_t)i] = pool_words[i];
         }
     }
-    if (b == 0 && c == h->P.N) { if (chain_recover(h)) return 1; }
-    else if (chain_failed(h, "cz_reset")) return 1;
     // persistent scratch of the handle (cz_create: three words per env; the observation staging is shared with cz_step / cz_observe)
     int32_t *const d_lay = h->d_reset_words;
     uint32_t *const d_rec = (uint32_t *)h->d_reset_words + h->P.N, *const d_pool = (uint32_t *)h->d_reset_words + 2 * (size_t)h->P.N;
@@ -1052,12 +948,42 @@ extern "C" int cz_observe(cz_handle h, int64_t b, int64_t c, double *obs) {
     if (c == 0) return 0;
     if (!obs) return fail(h, "cz_observe: null buffer");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    if (chain_failed(h, "cz_observe")) return 1;
     size_t ob = (size_t)c * h->P.A * h->P.F * 8;
     if (!h->d_obs) HIPCHK(h, hipMalloc(&h->d_obs, (size_t)h->P.N * h->P.A * h->P.F * 8));
     Params P = h->P;
-    hipError_t rc = h->kl.observe(P, h->stream, b, (int)c, h->d_obs);
+    hipError_t rc = h->kl.observe(P, h->stream, b, (int)c, h->d_obs, nullptr);
     if (rc == hipSuccess) rc = hipMemcpyAsync(obs, h->d_obs, ob, hipMemcpyDeviceToHost, h->stream);
+    const hipError_t rs = hipStreamSynchronize(h->stream);
+    HIPCHK(h, rc);
+    HIPCHK(h, rs);
+    return 0;
+}
+
+// observe() of the current state into DEVICE buffers, float64 rows and / or the compact form (either may be NULL): what a consumer
+// that stays on the device needs after cz_reset / cz_set_state, before the first step has written anything.  Stream-ordered,
+// no synchronisation (legal inside a stream capture of the caller).
+extern "C" int cz_observe_device(cz_handle h, int64_t b, int64_t c, double *d_obs, uint8_t *d_codes) {
+    if (ready(h) || check_range(h, b, c)) return 1;
+    if (c == 0) return 0;
+    if (!d_obs && !d_codes) return fail(h, "cz_observe_device: both output pointers are null");
+    if (set_device(h)) return 1;
+    Params P = h->P;
+    P.wt = 0;
+    HIPCHK(h, h->kl.observe(P, h->stream, b, (int)c, d_obs, d_codes));
+    return 0;
+}
+// ... the compact form into a host buffer: codes uint8 [count][A][cz_codes_pitch] (cz_obs_table()[code] is the float64 feature)
+extern "C" int cz_observe_compact(cz_handle h, int64_t b, int64_t c, uint8_t *codes) {
+    if (ready(h) || check_range(h, b, c)) return 1;
+    if (c == 0) return 0;
+    if (!codes) return fail(h, "cz_observe_compact: null buffer");
+    if (set_device(h)) return 1;
+    const size_t row = (size_t)h->P.A * codes_pitch(h->P.F);
+    if (!h->d_codes_stage) HIPCHK(h, hipMalloc(&h->d_codes_stage, (size_t)h->P.N * row));
+    Params P = h->P;
+    P.wt = 0;
+    hipError_t rc = h->kl.observe(P, h->stream, b, (int)c, nullptr, (uint8_t *)h->d_codes_stage);
+    if (rc == hipSuccess) rc = hipMemcpyAsync(codes, h->d_codes_stage, (size_t)c * row, hipMemcpyDeviceToHost, h->stream);
     const hipError_t rs = hipStreamSynchronize(h->stream);
     HIPCHK(h, rc);
     HIPCHK(h, rs);
@@ -1077,7 +1003,7 @@ extern "C" int cz_step_device(cz_handle h, const int32_t *d_actions, double *d_o
     if (ready(h)) return 1;
     if (!d_actions) return fail(h, "cz_step_device: actions pointer is null");
     if (set_device(h)) return 1;
-    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
+    if (!h->upd_ranges.empty() && !caller_capturing(h) && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
     Params P = h->P;
     P.actions = d_actions; P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
     P.marks_out = h->marks_out_next; h->marks_out_next = nullptr;
@@ -1090,7 +1016,7 @@ extern "C" int cz_step_device_compact(cz_handle h, const int32_t *d_actions, uin
     if (ready(h)) return 1;
     if (!d_actions || !d_codes) return fail(h, "cz_step_device_compact: actions and codes pointers must not be null");
     if (set_device(h)) return 1;
-    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;
+    if (!h->upd_ranges.empty() && !caller_capturing(h) && flush_updates(h, false)) return 1;
     Params P = h->P;
     P.actions = d_actions; P.obs = d_obs; P.codes = d_codes; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
     return launch_step(h, P);
@@ -1121,12 +1047,11 @@ extern "C" int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_acti
     if (ready(h)) return 1;
     if (!d_actions || K < 1 || action_period < 1) return fail(h, "cz_step_device_many: bad arguments");
     if (set_device(h)) return 1;
-    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
+    if (!h->upd_ranges.empty() && !caller_capturing(h) && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
     Params P = h->P;
     P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
     P.actions = d_actions;
     if (ring_fusable(h, P, K, action_stride)) return launch_ring_fused(h, P, K, d_actions, action_stride, action_period, 0);   // cz_set_ring_fused
-    if (K >= 2 && chainable(h, P)) return launch_chain(h, P, K, d_actions, action_stride, action_period, 0);   // cz_set_overlap
     for (int32_t k = 0; k < K; ++k) {
         P.actions = d_actions + (int64_t)(k % action_period) * action_stride;
         if (launch_step(h, P)) return 1;
@@ -1201,6 +1126,7 @@ static bool ring_fusable(cz_handle h, const Params &P, int32_t K, int64_t stride
 static int launch_ring_fused(cz_handle h, Params &P, int32_t K, const int32_t *d_ring, int64_t stride, int32_t period, int32_t first_slot) {
     // (the kernel addresses the action rows with 32-bit byte offsets from the first row of the launch)
     const int64_t max_T = (int64_t)(0xFFFFFFFFull / ((uint64_t)P.N * (uint64_t)P.A * 4ull));
+    if (max_T < 1) return fail(h, "fused ring run: one action row of %d envs x %d agents exceeds the 4 GiB the kernel addresses", P.N, P.A);
     int32_t k = 0;
     while (k < K) {
         const int32_t slot = (int32_t)(((int64_t)first_slot + k) % period);
@@ -1212,6 +1138,7 @@ static int launch_ring_fused(cz_handle h, Params &P, int32_t K, const int32_t *d
         Q.T = (int32_t)run; Q.seed = 0; Q.step0 = 1u;          // bit 0: outputs in place
         if (launch_step(h, Q, nullptr, true)) return 1;
         k += (int32_t)run;
+        h->n_ring_fused_launches++;
     }
     h->n_ring_fused_steps += K;
     return 0;
@@ -1222,11 +1149,9 @@ static int ring_walk(cz_handle h, int32_t K, const int32_t *d_ring, int64_t stri
     Params P = h->P;
     P.obs = d_obs; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc; P.T = 1;
     P.actions = d_ring;
-    // (overlapped runs are launched directly: captured into a graph as two parallel chains they still overlap, but replay
-    // costs 0.2 us per launch more and a 20-step region 1 us per step more than direct launches on two streams)
     if (ring_fusable(h, P, K, stride)) return launch ? launch_ring_fused(h, P, K, d_ring, stride, period, first_slot) : 0;
-    if (K >= 2 && chainable(h, P)) return launch ? launch_chain(h, P, K, d_ring, stride, period, first_slot) : 0;
-    const bool graphs = ring_select(h, d_ring, stride, period, d_obs, d_rewards, d_term, d_trunc);
+    // (inside a capture of the caller: plain launches - a capture of the library's own cannot nest in it)
+    const bool graphs = !caller_capturing(h) && ring_select(h, d_ring, stride, period, d_obs, d_rewards, d_term, d_trunc);
     int32_t k = 0;
     while (k < K) {
         const int32_t slot = (int32_t)(((int64_t)first_slot + k) % period);
@@ -1274,58 +1199,13 @@ extern "C" int cz_step_device_ring(cz_handle h, int32_t K, const int32_t *d_ring
     if (ready(h)) return 1;
     if (!d_ring || K < 1 || period < 1 || first_slot < 0 || first_slot >= period) return fail(h, "cz_step_device_ring: bad arguments");
     if (set_device(h)) return 1;
-    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
+    if (!h->upd_ranges.empty() && !caller_capturing(h) && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
     return ring_walk(h, K, d_ring, stride, period, first_slot, d_obs, d_rewards, d_term, d_trunc, true);
-}
-// the largest batch (envs of this handle's kernel) that two overlapped launches fit the device with; larger batches never overlap
-extern "C" int64_t cz_overlap_limit(cz_handle h) { return h ? h->chain_max_envs : 0; }
-// Overlapped launches on / off for this handle (off by default; CZ_CHAIN=1 switches them on at cz_create when no other
-// handle of the device has them).  One handle per device and process: the waiting kernels of two handles together could
-// fill the device, which is what cz_overlap_limit rules out for one.  Returns the previous setting, or -1 (see
-// cz_last_error) when another handle of this device holds the right.
-static std::atomic<cz_handle> g_overlap_owner[64];
-extern "C" int cz_set_overlap(cz_handle h, int32_t enabled) {
-    if (!h) { fail(nullptr, "null handle"); return -1; }
-    const int was = h->chain_enabled ? 1 : 0;
-    std::atomic<cz_handle> &owner = g_overlap_owner[h->cfg.device_id & 63];
-    if (enabled && !was) {
-        cz_handle none = nullptr;
-        if (!owner.compare_exchange_strong(none, h)) {
-            fail(h, "cz_set_overlap: another handle of device %d already overlaps its runs (one per device and process)", h->cfg.device_id);
-            return -1;
-        }
-        if (!h->aux_stream) {       // first use: the second stream, the fork event, the pinned word a timed-out hand-off sets
-            void *dp = nullptr;
-            if (hipSetDevice(h->cfg.device_id) != hipSuccess || hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipHostMalloc((void **)&h->h_chain_err, 64, hipHostMallocMapped) != hipSuccess ||
-                hipHostGetDevicePointer(&dp, h->h_chain_err, 0) != hipSuccess) {
-                owner.store(nullptr);
-                fail(h, "cz_set_overlap: could not create the second stream");
-                return -1;
-            }
-            *h->h_chain_err = 0;
-#ifdef CZ_PROFILE
-            owner.store(nullptr);
-            fail(h, "cz_set_overlap: not available in the diagnostic build");
-            return -1;
-#else
-            h->P.chain_err = (uint32_t *)dp;
-#endif
-            h->tables_version++;
-        }
-        h->chain_enabled = true;
-    } else if (!enabled && was) {
-        h->chain_enabled = false;
-        cz_handle me = h;
-        owner.compare_exchange_strong(me, nullptr);
-    }
-    return was;
 }
 // Runs of cz_step_device_ring / cz_step_device_many as FUSED launches (opt-in): the K steps of a run whose action slots are densely
 // packed go out as one launch per stretch of consecutive slots, the env state staying in registers across the steps and every
 // step's outputs written to the caller's [N][A] buffers in place - the same final state, outputs and statistics as K launches,
-// without launch boundaries or sequence words.  Returns the previous setting.
+// without launch boundaries.  Returns the previous setting.
 extern "C" int cz_set_ring_fused(cz_handle h, int32_t enabled) {
     if (!h) { fail(nullptr, "null handle"); return -1; }
     const int was = h->ring_fused ? 1 : 0;
@@ -1337,13 +1217,6 @@ extern "C" int64_t cz_ring_fused_steps(cz_handle h, int32_t reset) {
     const int64_t n = h->n_ring_fused_steps;
     if (reset) h->n_ring_fused_steps = 0;
     return n;
-}
-// how many step kernels of this handle went out as overlapped launches (cz_step_device_ring only); reset != 0 zeroes it
-extern "C" int cz_chain_counts(cz_handle h, int64_t *chained_kernels, int32_t reset) {
-    if (!h) return fail(nullptr, "null handle");
-    if (chained_kernels) *chained_kernels = h->n_chained_kernels;
-    if (reset) h->n_chained_kernels = 0;
-    return 0;
 }
 // how many step kernels of this handle were replayed from graphs / launched directly (cz_step_device_ring only);
 // reset != 0 zeroes the counters after reading
@@ -1364,7 +1237,7 @@ extern "C" int cz_rollout(cz_handle h, int32_t T, uint64_t seed, uint32_t step0,
         return fail(h, "cz_rollout: T * num_envs * num_agents * 8 must stay below 4 GiB (T <= %llu here): split the rollout",
                     (unsigned long long)(0xFFFFFFFFull / ((uint64_t)h->P.N * h->P.A * 8ull)));
     if (set_device(h)) return 1;
-    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
+    if (!h->upd_ranges.empty() && !caller_capturing(h) && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
     Params P = h->P;
     P.actions = nullptr; P.obs = d_obs; P.codes = nullptr; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc;
     P.T = T; P.seed = seed; P.step0 = step0;
@@ -1381,7 +1254,7 @@ extern "C" int cz_rollout_compact(cz_handle h, int32_t T, uint64_t seed, uint32_
         return fail(h, "cz_rollout_compact: T * num_envs * num_agents * 8 must stay below 4 GiB (T <= %llu here): split the rollout",
                     (unsigned long long)(0xFFFFFFFFull / ((uint64_t)h->P.N * h->P.A * 8ull)));
     if (set_device(h)) return 1;
-    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;
+    if (!h->upd_ranges.empty() && !caller_capturing(h) && flush_updates(h, false)) return 1;
     Params P = h->P;
     P.actions = nullptr; P.obs = d_obs; P.codes = d_codes; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc;
     P.T = T; P.seed = seed; P.step0 = step0;
@@ -1390,7 +1263,7 @@ extern "C" int cz_rollout_compact(cz_handle h, int32_t T, uint64_t seed, uint32_
 
 // The same fused launch over actions of the caller: d_actions int32 [T][N][A], step t of env e reads row t.  What replay and
 // open-loop search use instead of T one-step launches: the record stays in registers, every step's outputs land in the
-// trajectory buffers, and nothing has to be ordered between launches (so no overlapped mode is needed for it either).
+// trajectory buffers, and nothing has to be ordered between launches .
 extern "C" int cz_rollout_actions(cz_handle h, int32_t T, const int32_t *d_actions, double *d_obs, double *d_rewards,
                                   uint8_t *d_term, uint8_t *d_trunc) {
     if (ready(h)) return 1;
@@ -1400,7 +1273,7 @@ extern "C" int cz_rollout_actions(cz_handle h, int32_t T, const int32_t *d_actio
         return fail(h, "cz_rollout_actions: T * num_envs * num_agents * 8 must stay below 4 GiB (T <= %llu here): split the rollout",
                     (unsigned long long)(0xFFFFFFFFull / ((uint64_t)h->P.N * h->P.A * 8ull)));
     if (set_device(h)) return 1;
-    if (!h->upd_ranges.empty() && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
+    if (!h->upd_ranges.empty() && !caller_capturing(h) && flush_updates(h, false)) return 1;      // a staged layout update whose time may have come
     Params P = h->P;
     P.actions = d_actions; P.obs = d_obs; P.codes = nullptr; P.rewards = d_rewards; P.term = d_term; P.trunc = d_trunc;
     P.T = T; P.seed = 0; P.step0 = 0;
@@ -1594,6 +1467,22 @@ extern "C" int cz_probe_closed_loop(cz_handle h, int32_t K, int32_t reps, int32_
     return 0;
 }
 
+// Test / measurement aid: ONE launch of that stand-in policy on the handle's stream - d_actions[env][agent] = hash of four features of
+// the observation in d_obs (float64 rows) or, with d_obs NULL, in d_codes (compact rows; same actions).  What a caller's policy
+// kernel is in tests/test_gpu_capture.py: [cz_probe_policy, cz_step_device] captured into a graph of the CALLER.
+extern "C" int cz_probe_policy(cz_handle h, const double *d_obs, const uint8_t *d_codes, int32_t *d_actions) {
+    if (ready(h)) return 1;
+    if (!d_actions || (!d_obs && !d_codes)) return fail(h, "cz_probe_policy: bad arguments");
+    if (set_device(h)) return 1;
+    const int rows = h->P.N * h->P.A;
+    const uint32_t n_actions = h->P.scheme == 3 ? 5u : 8u;
+    if (d_obs) hipLaunchKernelGGL(k_probe_policy, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, d_obs, d_actions, rows, h->P.F, n_actions);
+    else hipLaunchKernelGGL(k_probe_policy_codes, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, d_codes, h->d_lut, d_actions, rows,
+                            h->P.F, codes_pitch(h->P.F), n_actions);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 // ... the same closed loop for a consumer of the compact observation: cz_step_device_compact (codes only, no float64 rows), then
 // the policy kernel that reads the codes
 extern "C" int cz_probe_closed_loop_compact(cz_handle h, int32_t K, int32_t reps, int32_t *d_actions, uint8_t *d_codes, double *d_rewards,
@@ -1633,20 +1522,6 @@ extern "C" int cz_probe_closed_loop_compact(cz_handle h, int32_t K, int32_t reps
     (void)hipGraphExecDestroy(ge);
     HIPCHK(h, rc);
     *us_per_step = ms * 1e3f / (float)((int64_t)reps * K);
-    return 0;
-}
-
-// Test aid: `workgroups` workgroups of a foreign kernel (512 threads, 34 KB of LDS each, like the step kernel's) that hold
-// their slots for `microseconds`, launched on a stream of its own that nothing else of this handle is ordered on; returns at
-// once.  What a caller's own long-running kernels do to a device that an overlapped run (cz_set_overlap) counts on having for
-// itself: tests/test_gpu_large.py runs one under such a run and checks the documented outcome.
-extern "C" int cz_probe_occupy(cz_handle h, int32_t workgroups, int32_t microseconds) {
-    if (!h || workgroups < 1 || microseconds < 0) return fail(h, "cz_probe_occupy: bad arguments");
-    HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    if (!h->foreign_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->foreign_stream, hipStreamNonBlocking));
-    hipLaunchKernelGGL(k_probe_occupy, dim3((unsigned)workgroups), dim3(64 * ENVS_PER_WG), 0, h->foreign_stream,
-                       (unsigned long long)microseconds * 100ull, (int *)nullptr);
-    HIPCHK(h, hipGetLastError());
     return 0;
 }
 
@@ -1693,7 +1568,7 @@ extern "C" int cz_memcpy_d2h(cz_handle h, void *d, const void *s, size_t n) {
     if (!h) return fail(nullptr, "null handle");
     HIPCHK(h, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return chain_failed(h, "cz_memcpy_d2h");
+    return 0;
 }
 extern "C" int cz_timer_start(cz_handle h) {
     if (!h) return fail(nullptr, "null handle");
@@ -1705,7 +1580,7 @@ extern "C" int cz_timer_stop(cz_handle h, float *ms) {
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev1));
     HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
-    return chain_failed(h, "cz_timer_stop");
+    return 0;
 }
 extern "C" int cz_kernel_time_reset(cz_handle h, int32_t enable) {
     if (!h) return fail(nullptr, "null handle");
@@ -1745,7 +1620,7 @@ extern "C" int cz_get_stats(cz_handle h, cz_stats *out) {
     if (stats_reduce(h)) return 1;
     HIPCHK(h, hipMemcpyAsync(out, h->d_stats_out, sizeof(cz_stats), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return chain_failed(h, "cz_get_stats");
+    return 0;
 }
 extern "C" int cz_reset_stats(cz_handle h) {
     if (!h) return fail(nullptr, "null handle");
@@ -1831,7 +1706,7 @@ extern "C" int cz_stats_allgather(cz_handle h, cz_stats *out) {
     if (r) return fail(h, "ncclAllGather failed: %d", r);
     HIPCHK(h, hipMemcpyAsync(out, h->d_gather, sizeof(cz_stats) * (size_t)h->n_ranks, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return chain_failed(h, "cz_stats_allgather");
+    return 0;
 }
 
 // Barrier over the communicator: a 4-byte RCCL all-reduce on the handle's stream, then a stream synchronisation.  Every

@@ -83,28 +83,17 @@ struct Params {
 #ifdef CZ_ABLATE
     int32_t stop, stop_pad;        // ablation build only: phase index after which the kernel returns (CZ_STOP), else -1
 #endif
-    // (the argument block is 56 + 264 bytes = five 64-byte lines exactly; one more field costs every launch a sixth)
+    // (the argument block: 56 bytes of leading scalars + this struct, within five 64-byte lines; a sixth line costs every launch)
 #ifdef CZ_PROFILE
-    unsigned long long *stamps;    // diagnostic build only: [N][8] s_memtime stamps (that build does not overlap launches)
-#else
-    uint32_t *chain_err;           // pinned host word: an overlapped launch whose hand-off never came sets it (cz_sync fails on it)
+    unsigned long long *stamps;    // diagnostic build only: [N][8] s_memtime stamps
 #endif
-    uint32_t seq;                  // per-env hand-off of overlapped launches (SEQ_*); travels as a leading scalar argument
 #ifdef CZ_TIMELINE
     unsigned long long *timeline;  // timeline build only (make timeline): [N][2] entry / exit stamps of this launch's waves, or nullptr
 #endif
 };
-#if !defined(CZ_TIMELINE) && !defined(CZ_ABLATE)
-static_assert(sizeof(Params) == 264, "argument block: see the note above");
+#if !defined(CZ_TIMELINE) && !defined(CZ_ABLATE) && !defined(CZ_PROFILE)
+static_assert(sizeof(Params) <= 264 && sizeof(Params) % 8 == 0, "argument block: see the note above");
 #endif
-// Overlapped ("chained") launches: consecutive step kernels of a run go to two streams alternately, so a kernel may start
-// while its predecessor still runs; what orders them is a sequence word per env (64 B apart, right behind the records):
-// a wave waits until its env's word equals the launch's number, steps, and publishes number + 1.  The launch boundary
-// (1.6 us + start skew on this part) then hides behind the other kernel's work.  Everything a step reads of its
-// predecessor's (the record, the per-env statistics) therefore moves with device-scope loads and write-through stores:
-// the L2 of another XCD is not coherent for ordinary accesses between launch boundaries.
-constexpr uint32_t SEQ_PUBLISH = 1u << 31, SEQ_WAIT = 1u << 30, SEQ_MASK = SEQ_WAIT - 1u;
-constexpr int SEQ_STRIDE_WORDS = 16;
 
 #ifndef CZ_PRIO
 #define CZ_PRIO 1
@@ -154,7 +143,7 @@ enum : uint32_t { LC_GROUPS = 0, LC_ACTIVE = 1 };
 // The reference draws from numpy's process-global stream, which defines the draws of ONE world per process; a batch takes every
 // draw from a counter-based stream keyed by (seed, global env id, episode << 32 | t, agent, draw index) instead - the same
 // function as cooking_zoo_amd/spawn.py `uniform` - so results depend neither on the batch size nor on the sharding nor on how
-// the steps are launched (one per launch, overlapped, fused).  The record's status word carries one "despawned" bit per agent
+// the steps are launched (one per launch, fused).  The record's status word carries one "despawned" bit per agent
 // (bit 8 + a) and five bits of grace countdown each (from bit 12 + 5 a).  The parameters live in device memory behind the
 // quotient table.
 struct SpawnCfg {

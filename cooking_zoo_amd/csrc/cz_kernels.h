@@ -87,59 +87,34 @@ __device__ __forceinline__ void stg_wt(void *sbase, uint32_t voff, T v) {
     __hip_atomic_store(reinterpret_cast<T *>(reinterpret_cast<char *>(sbase) + voff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// device-scope load (`global_load ... sc1`): does not hit a line that this XCD's L2 fetched before another XCD rewrote it.
-// Used, with stg_wt, for everything one step hands to the next (see SEQ_* in cz_device.h); after a launch boundary the L2
-// is cold anyway, so ordinary launches lose nothing.
-template <class T>
-__device__ __forceinline__ T ldg_dev(const void *sbase, uint32_t voff) {
-    return __hip_atomic_load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(sbase) + voff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 
 // Loads are clamped instead of exec-masked (no branches): every address stays inside the record.
-// `dev` (wave-uniform): the launch is part of an overlapped run -> device-scope flavour; ordinary launches keep cached
-// loads and write-back stores (the launch boundary publishes them), which is 0.7 us per launch faster there
-template <class T>
-__device__ __forceinline__ T ldrec(bool dev, const void *sbase, uint32_t voff) {
-    if (dev) return ldg_dev<T>(sbase, voff);
-    return ldg<T>(sbase, voff);
-}
-template <class T>
-__device__ __forceinline__ void strec(bool dev, void *sbase, uint32_t voff, T v) {
-    if (dev) stg_wt<T>(sbase, voff, v);
-    else stg<T>(sbase, voff, v);
-}
 template <int OPL, int CPL, int NA>
-__device__ __forceinline__ void load_env(const Params &P, Env<OPL, CPL, NA> &e, const Ctx &cx, const uint32_t *__restrict__ rec, bool dev = false) {
+__device__ __forceinline__ void load_env(const Params &P, Env<OPL, CPL, NA> &e, const Ctx &cx, const uint32_t *__restrict__ rec) {
     const uint32_t lane = (uint32_t)cx.lane;
-    // header words: wave-uniform.  Ordinary launches read them with one scalar load (nothing in this kernel writes a record
-    // before its loads are done, and the scalar cache is cold at kernel start like every other cache); an overlapped launch
-    // needs the device-scope flavour, which only vector loads have: eight lanes load, v_readlane spreads
+    // header words: wave-uniform, one scalar load (nothing in this kernel writes a record before its loads are done, and the
+    // scalar cache is cold at kernel start like every other cache)
     uint32_t hw[HDR_WORDS];
-    if (!dev) {
+    {
         typedef const __attribute__((address_space(4))) uint32_t *kconst_u32;
         const kconst_u32 hp = (kconst_u32)rec;
 #pragma unroll
         for (int i = 0; i < HDR_WORDS; ++i) hw[i] = hp[i];
-    } else {
-        const uint32_t h = ldg_dev<uint32_t>(rec, (lane & 7u) * 4u);
-#pragma unroll
-        for (int i = 0; i < HDR_WORDS; ++i) hw[i] = rdl(h, i);
     }
-    const uint32_t aw = ldrec<uint32_t>(dev, rec, (AGENT_WORD0 + (lane & 3u)) * 4u);        // agent words, lane a = agent a
+    const uint32_t aw = ldg<uint32_t>(rec, (AGENT_WORD0 + (lane & 3u)) * 4u);        // agent words, lane a = agent a
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const uint32_t c = lane + 64u * k;
-        const uint32_t v = ldrec<uint8_t>(dev, rec, CELL_WORD0 * 4u + min(c, (uint32_t)cx.C - 1u));
+        const uint32_t v = ldg<uint8_t>(rec, CELL_WORD0 * 4u + min(c, (uint32_t)cx.C - 1u));
         e.cell[k] = (c < (uint32_t)cx.C) ? v : 0u;
     }
 #pragma unroll
     for (int k = 0; k < OPL; ++k) {
         const uint32_t s = lane + 64u * k, sc = min(s, (uint32_t)cx.D - 1u);
-        const uint32_t a = ldrec<uint32_t>(dev, rec, ((uint32_t)P.dyn0_off + sc) * 4u), b = ldrec<uint32_t>(dev, rec, ((uint32_t)P.dyn1_off + sc) * 4u);
+        const uint32_t a = ldg<uint32_t>(rec, ((uint32_t)P.dyn0_off + sc) * 4u), b = ldg<uint32_t>(rec, ((uint32_t)P.dyn1_off + sc) * 4u);
         e.d0[k] = (s < (uint32_t)cx.D) ? a : 0u;
         e.d1[k] = (s < (uint32_t)cx.D) ? b : 0u;
     }
@@ -155,10 +130,9 @@ __device__ __forceinline__ void load_env(const Params &P, Env<OPL, CPL, NA> &e, 
 }
 
 // header + agents in one 12-lane store (v_writelane assembles the words), cells / objects only when they changed;
-// (`dev`: write-through stores, the next step of this env may run on another XCD before the next launch boundary, SEQ_*)
 template <int OPL, int CPL, int NA>
 __device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t *__restrict__ rec,
-                                          bool cells_dirty, bool objs_dirty, bool header_dirty = true, bool dev = false) {
+                                          bool cells_dirty, bool objs_dirty, bool header_dirty = true) {
     const uint32_t lane = (uint32_t)cx.lane;
     if (header_dirty) {
         uint32_t h = 0;
@@ -170,16 +144,16 @@ __device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL, N
         h = wrl(e.recipes, W_RECIPES, h);
         h = wrl(e.pool, W_POOL, h);
         h = wrl(e.marks_hi, W_MARKS_HI, h);
-        if (lane < (uint32_t)HDR_WORDS) strec<uint32_t>(dev, rec, lane * 4u, h);
+        if (lane < (uint32_t)HDR_WORDS) stg<uint32_t>(rec, lane * 4u, h);
     } else if (lane == 0u) {
-        strec<uint32_t>(dev, rec, W_T * 4u, e.t);                          // the step counter is all that changed (the usual case)
+        stg<uint32_t>(rec, W_T * 4u, e.t);                          // the step counter is all that changed (the usual case)
     }
-    if (lane < (uint32_t)MAX_AGENTS) strec<uint32_t>(dev, rec, (AGENT_WORD0 + lane) * 4u, e.agw);
+    if (lane < (uint32_t)MAX_AGENTS) stg<uint32_t>(rec, (AGENT_WORD0 + lane) * 4u, e.agw);
     if (cells_dirty) {
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
             const uint32_t c = lane + 64u * k;
-            if (c < (uint32_t)cx.C) strec<uint8_t>(dev, rec, CELL_WORD0 * 4u + c, (uint8_t)e.cell[k]);
+            if (c < (uint32_t)cx.C) stg<uint8_t>(rec, CELL_WORD0 * 4u + c, (uint8_t)e.cell[k]);
         }
     }
     if (objs_dirty) {
@@ -187,8 +161,8 @@ __device__ __forceinline__ void store_env(const Params &P, const Env<OPL, CPL, N
         for (int k = 0; k < OPL; ++k) {
             const uint32_t s = lane + 64u * k;
             if (s < (uint32_t)cx.D) {
-                strec<uint32_t>(dev, rec, ((uint32_t)P.dyn0_off + s) * 4u, e.d0[k]);
-                strec<uint32_t>(dev, rec, ((uint32_t)P.dyn1_off + s) * 4u, e.d1[k]);
+                stg<uint32_t>(rec, ((uint32_t)P.dyn0_off + s) * 4u, e.d0[k]);
+                stg<uint32_t>(rec, ((uint32_t)P.dyn1_off + s) * 4u, e.d1[k]);
             }
         }
     }
@@ -635,22 +609,18 @@ struct Early {
     const int32_t *actions;        // Params::actions
     const double *lut;             // Params::lut
     int32_t N, RW, W, H, D, dyn0_off, dyn1_off;
-    uint32_t seq;                  // Params::seq (SEQ_* flags | launch number)
 };
 __host__ __device__ inline Early early_of(const Params &P) {
-    return Early{P.state, P.actions, P.lut, P.N, P.RW, P.W, P.H, P.D, P.dyn0_off, P.dyn1_off, P.seq};
+    return Early{P.state, P.actions, P.lut, P.N, P.RW, P.W, P.H, P.D, P.dyn0_off, P.dyn1_off};
 }
 
-// CHAIN = true: the one-step kernel of an overlapped run (SEQ_* in cz_device.h) -- its own kernel (k_step_chain below),
-// so that the ordinary kernel keeps its argument list and a prologue free of branches (a branch in front of the loads
-// costs 0.8 us per launch there)
-template <int OPL, int CPL, int NA, int SCHEME, int FUSED_MODE, bool CHAIN>
+template <int OPL, int CPL, int NA, int SCHEME, int FUSED_MODE>
 __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
                                             int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
-                                            int32_t e_dyn1, uint32_t e_seq, const Params &P0) {
+                                            int32_t e_dyn1, const Params &P0) {
 #ifdef CZ_TIMELINE
     // Timeline build (make timeline -> libcookingzoo_hip_tl.so): the shipped kernel plus two reads of the device-wide 100 MHz
-    // clock per wave - at its first instruction and behind its last store (for an overlapped launch: behind the publish) - and
+    // clock per wave - at its first instruction and behind its last store - and
     // one 16-byte store of lane 0.  No waits are added in between (unlike the phase stamps of `make prof`).
     const uint64_t tl_in = wall_clock64();
 #ifdef CZ_TL_CLOCK
@@ -687,70 +657,22 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     CZ_STAMP(0);
     uint32_t *rec = P.state + (uint32_t)env * (uint32_t)P.RW;        // (cz_create: the records of a handle stay below 4 GiB)
     double *retp = reinterpret_cast<double *>(rec + RET_WORD0);
-    // ---- an overlapped launch first waits for its env's predecessor (SEQ_* in cz_device.h); ordinary launches skip this
-    uint32_t *const seqw = P.state + (size_t)P.N * P.RW + (size_t)env * SEQ_STRIDE_WORDS;
     constexpr bool FUSED = FUSED_MODE == 1 || FUSED_MODE == 2 || FUSED_MODE == 4 || FUSED_MODE == 5, EXT = FUSED_MODE == 2;
     constexpr bool CODES = FUSED_MODE == 3 || FUSED_MODE == 4 || FUSED_MODE == 5;
     // mode 5: a fused rollout that writes codes ONLY (cz_rollout_compact without a float64 trajectory).  Without the float64 path -
     // its six descriptor registers, its encode - the codes' own descriptor words fit the registers for the whole launch (mode 4 reloads
     // them every step: held there they cost 136 vector registers, three waves per SIMD)
     constexpr bool CODES_ONLY = FUSED_MODE == 5;
-    static_assert(!(FUSED && CHAIN), "overlapped launches are one-step launches");
-    constexpr bool chained = CHAIN;
-    bool abandoned = false;
     int av = 0;
-    if (CHAIN) {
-        // What does not depend on the predecessor happens before the wait: the actions, the constant part of the LDS image
-        // and the workgroup's table with its barrier.  With the barrier in front of the wait the eight envs of a workgroup
-        // stay independent - behind it, every one of them would start only when the slowest of the eight predecessors is done.
-        av = ldg<int>(P.actions, ((uint32_t)env * (uint32_t)NA + (uint32_t)min(lane, NA - 1)) * 4u);
-        init_lds<CPL>(P, cx, lds);
-        if (threadIdx.x < (unsigned)LUT_SIZE) lut[threadIdx.x] = lutv;
-        __syncthreads();
-    }
-    if (CHAIN && (e_seq & SEQ_WAIT) && env_raw < P.N) {
-        const uint32_t want = e_seq & SEQ_MASK;
-        uint32_t polls = 0;
-        uint64_t t_begin = 0;
-#ifndef CZ_POLL_SLEEP
-#define CZ_POLL_SLEEP 1
-#endif
-        while (rfl(ldg_dev<uint32_t>(seqw, 0)) != want) {
-            if (CZ_POLL_SLEEP > 0) __builtin_amdgcn_s_sleep(CZ_POLL_SLEEP);
-            if ((++polls & 255u) == 0u) {                   // ~every 50 us: somebody else gave up, or two seconds have passed
-                const uint64_t now = wall_clock64();        // 100 MHz
-                if (t_begin == 0) t_begin = now;
-#ifdef CZ_PROFILE                // (the diagnostic build has no such word and never launches this kernel: cz_set_overlap refuses)
-                uint32_t *const errw = reinterpret_cast<uint32_t *>(CZ_LATE_STEP()->stamps);
-#else
-                uint32_t *const errw = CZ_LATE_STEP()->chain_err;
-#endif
-                const uint32_t seen = rfl(ldg_dev<uint32_t>(errw, 0));
-                if (seen != 0u || now - t_begin > 200000000ull) {
-                    // first reporter: what it waited for (low 24 bits), what it last saw there (next 6), bit 31
-                    if (lane == 0 && seen == 0u)
-                        __hip_atomic_store(errw, 0x80000000u | ((rfl(ldg_dev<uint32_t>(seqw, 0)) & 63u) << 24) | (want & 0xFFFFFFu), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_SYSTEM);
-                    abandoned = true;
-                    break;
-                }
-            }
-        }
-    }
-    // (Ordering of the hand-off: the poll's load has returned - its value was read by the branch above - before any load
-    // below is issued; those are device-scope loads (sc1), served from behind the XCDs' L2s like the predecessor's
-    // write-through stores, which were acknowledged before it published.  So no acquire fence is needed by the hardware - an
-    // agent-scope one would invalidate the L2 on every poll - but the compiler must not move the loads up:)
-    if (CHAIN) asm volatile("" ::: "memory");
 #ifdef CZ_TIMELINE
-    const uint64_t tl_seen = wall_clock64();        // (an overlapped launch: its predecessor's number has been seen)
+    const uint64_t tl_seen = wall_clock64();
 #endif
     // ---- every load of the step is issued here, before anything waits
-    if (!FUSED && !CHAIN) av = ldg<int>(P.actions, ((uint32_t)env * (uint32_t)NA + (uint32_t)min(lane, NA - 1)) * 4u);
-    double ret = ldrec<double>(chained, retp, ((uint32_t)lane & 3u) * 8u);                                       // running episode return, lane a = agent a
+    if (!FUSED) av = ldg<int>(P.actions, ((uint32_t)env * (uint32_t)NA + (uint32_t)min(lane, NA - 1)) * 4u);
+    double ret = ldg<double>(retp, ((uint32_t)lane & 3u) * 8u);                                       // running episode return, lane a = agent a
     Env<OPL, CPL, NA> e;
-    load_env(P, e, cx, rec, chained);
-    if (!CHAIN) init_lds<CPL>(P, cx, lds);
+    load_env(P, e, cx, rec);
+    init_lds<CPL>(P, cx, lds);
     uint32_t rowv = load_recipe_rows(P, e.recipes, lane);
     uint32_t dsc[OBS_CHUNK];
     if (!CODES_ONLY && P.obs) load_desc(P, e.layout, 0, lane, dsc);
@@ -758,11 +680,9 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     const int64_t env_global = P.env_id_base + env;
     bool cells_dirty = false, objs_dirty = false, header_dirty = FUSED;
     bool img_objs = true, img_cells = true;                 // which parts of the LDS image the next encode must rebuild
-    if (!CHAIN) {
-        if (threadIdx.x < (unsigned)LUT_SIZE) lut[threadIdx.x] = lutv;
-        __syncthreads();
-    }
-    if (env_raw >= P.N || (CHAIN && abandoned)) return;
+    if (threadIdx.x < (unsigned)LUT_SIZE) lut[threadIdx.x] = lutv;
+    __syncthreads();
+    if (env_raw >= P.N) return;
     CZ_STAMP(1);
     // the compact observation's descriptor words (cz_step_device_compact): fetched here, behind the prologue's waits - a branch
     // on a late argument in front of the prologue's loads costs every launch 0.4 us - and hidden by the dynamics
@@ -784,11 +704,9 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
 #pragma nounroll
     for (int t = 0; t < T; ++t) {
         // The fused kernel re-reads its argument block every step (scalar loads that hit the constant cache): nothing of
-        // it then stays live across the loop's back edge, which is what used to spill ~90 SGPRs.  The kernel of overlapped
-        // launches, held to 96 scalar registers, does the same behind its wait (59 -> 24 spilled SGPRs together with the fresh
-        // lane number below).
+        // it then stays live across the loop's back edge, which is what used to spill ~90 SGPRs.
         Params Pt;
-        if (FUSED || CHAIN) {
+        if (FUSED) {
             static_assert(sizeof(Params) % 8 == 0, "copied as 64-bit words");
             typedef uint64_t __attribute__((may_alias)) word_t;
             const __attribute__((address_space(4))) word_t *src = (const __attribute__((address_space(4))) word_t *)CZ_LATE_STEP();
@@ -824,9 +742,6 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         if (Pt.stop == 2 || Pt.stop == 3) return;
 #endif
         CZ_STAMP(4);
-        // (overlapped launches: what the step's phases derived from the lane number - lane masks in scalar pairs - is not kept
-        // for the output phase but made again from an opaque copy: a compare costs less than a spill and a reload)
-        if (CHAIN) { asm volatile("" : "+v"(lane)); cx.lane = lane; }
         cells_dirty |= dt.cells != 0;
         objs_dirty |= (dt.touched | dt.interacted | dt.moved) != 0;
         header_dirty |= o.header;
@@ -842,8 +757,8 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         if (o.finished) {
             const uint32_t *su = kp->stat_u + (size_t)env * SU_WORDS;
             const double *sf = kp->stat_f + (size_t)env * SF_WORDS;
-            su_old = ldrec<uint32_t>(chained, su, ((uint32_t)lane & 15u) * 4u);
-            sf_old = ldrec<double>(chained, sf, (uint32_t)(SF_SUM0 + ((uint32_t)lane & 3u)) * 8u);
+            su_old = ldg<uint32_t>(su, ((uint32_t)lane & 15u) * 4u);
+            sf_old = ldg<double>(sf, (uint32_t)(SF_SUM0 + ((uint32_t)lane & 3u)) * 8u);
             ret_done = ret;
             ret = 0.0;
         }
@@ -870,20 +785,19 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
             double *const rewards = kp->rewards;
             uint8_t *const term = kp->term, *const trunc = kp->trunc;
             if (lane < NA) {
-                // (write-through in an overlapped run: the next launch rewrites the same bytes, possibly from another XCD)
-                if (!FUSED || rewards) strec<double>(chained, rewards, oidx * 8u, myrew);
-                if (!FUSED || term) strec<uint8_t>(chained, term, oidx, (uint8_t)o.term);
+                if (!FUSED || rewards) stg<double>(rewards, oidx * 8u, myrew);
+                if (!FUSED || term) stg<uint8_t>(term, oidx, (uint8_t)o.term);
                 if (!FUSED || trunc) {
-                    strec<uint8_t>(chained, trunc, oidx, (uint8_t)o.trunc);
+                    stg<uint8_t>(trunc, oidx, (uint8_t)o.trunc);
                     // whoever was despawned in this step is reported truncated once (cooking_env.py:344-349): a second store by
                     // those lanes, on the rare steps on which somebody leaves
-                    if (o.gone && ((o.gone >> lane) & 1u)) strec<uint8_t>(chained, trunc, oidx, (uint8_t)1);
+                    if (o.gone && ((o.gone >> lane) & 1u)) stg<uint8_t>(trunc, oidx, (uint8_t)1);
                 }
             }
         }
         if (!FUSED) {
             uint32_t *const marks_out = kp->marks_out;
-            if (marks_out && lane < 2) strec<uint32_t>(chained, marks_out, (2u * (uint32_t)env + (uint32_t)lane) * 4u, lane == 0 ? e.marks : e.marks_hi);   // infos["recipe_done"] of the host API
+            if (marks_out && lane < 2) stg<uint32_t>(marks_out, (2u * (uint32_t)env + (uint32_t)lane) * 4u, lane == 0 ? e.marks : e.marks_hi);   // infos["recipe_done"] of the host API
         }
         CZ_STAMP(5);
         img_objs |= (dt.touched | dt.moved) != 0;
@@ -902,20 +816,13 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
             const uint32_t root = Pt.wide ? (((a_of < 2u ? e.marks : e.marks_hi) >> (16u * (a_of & 1u))) & 1u) : ((e.marks >> (8u * (a_of & 3u))) & 1u);
             const uint32_t inc = lane == (int)SU_EPISODES ? 1u : lane == (int)SU_LENSUM ? e.t : lane == (int)SU_TRUNC ? (uint32_t)o.trunc
                                  : lane == (int)SU_TERM ? (uint32_t)o.term : a_of < (uint32_t)NA ? root : 0u;
-            if (lane < (int)SU_COMPLETED0 + NA && lane != (int)SU_STEPS) strec<uint32_t>(chained, su, (uint32_t)lane * 4u, su_old + inc);
-            if (lane < NA) strec<double>(chained, sf, (uint32_t)(SF_SUM0 + lane) * 8u, sf_old + ret_done);
+            if (lane < (int)SU_COMPLETED0 + NA && lane != (int)SU_STEPS) stg<uint32_t>(su, (uint32_t)lane * 4u, su_old + inc);
+            if (lane < NA) stg<double>(sf, (uint32_t)(SF_SUM0 + lane) * 8u, sf_old + ret_done);
         }
         CZ_STAMP(6);
     }
-    store_env(P, e, cx, rec, cells_dirty, objs_dirty, header_dirty, chained);
-    if (lane < NA) strec<double>(chained, retp, (uint32_t)lane * 8u, ret);
-    if (CHAIN) {
-        // Every store of this wave has been acknowledged at device scope before the successor may look.  (Handing the
-        // record over before the encode, with a second number that orders the observation stores of the two launches, was
-        // measured: 4.96 us per launch without that second wait, 7.95 us with it, against 5.15 us for this form.)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) stg_wt<uint32_t>(seqw, 0, ((e_seq & SEQ_MASK) + 1u) & SEQ_MASK);
-    }
+    store_env(P, e, cx, rec, cells_dirty, objs_dirty, header_dirty);
+    if (lane < NA) stg<double>(retp, (uint32_t)lane * 8u, ret);
     CZ_STAMP(7);
 #ifdef CZ_TIMELINE
     {
@@ -951,35 +858,8 @@ template <int OPL, int CPL, int NA, int SCHEME, int FUSED>
 __global__ __launch_bounds__(64 * envs_per_wg<CPL>()) CZ_STEP_ATTR void k_step(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
                                                           int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
                                                           int32_t e_dyn1, const Params P0) {
-    step_kernel<OPL, CPL, NA, SCHEME, FUSED, false>(e_state, e_actions, e_lut, e_N, e_RW, e_W, e_H, e_D, e_dyn0, e_dyn1, 0u, P0);
+    step_kernel<OPL, CPL, NA, SCHEME, FUSED>(e_state, e_actions, e_lut, e_N, e_RW, e_W, e_H, e_D, e_dyn0, e_dyn1, P0);
 }
-// Overlapped launches exist for the small instance only (one slot and one cell per lane: every shipped level): that is where
-// the gain was measured (4096 envs of the 7x7 levels), and the only instance that meets the eight-waves target below
-// without spilling vector registers - the 2 / 4 instance spilled 9-37 VGPRs to scratch under it, the 4 / 16 instance cannot
-// meet it at all - and there for up to three agents: with four the kernel needs 65 vector registers, one more than eight
-// waves per SIMD leave.  Batches of the larger instances are bound by their observation writes and replay graphs.
-template <int OPL, int CPL, int NA> constexpr bool chain_instance() { return OPL == 1 && CPL == 1 && NA <= 3; }
-// (one more leading scalar: the launch's sequence word; it fills the padding in front of P0, whose offset stays the same)
-// Eight waves per SIMD (<= 96 SGPRs, at the price of ~45 spilled ones): four workgroups per CU, so that two of these
-// kernels are resident IN FULL at the batch sizes that may overlap.  With the 106 SGPRs the compiler takes by itself only
-// three workgroups fit a CU, a waiting kernel (512 workgroups at 4096 envs) then leaves its predecessor a third of the
-// device, and on some boxes the predecessor's queued workgroups did not get in for seconds (hand-off timeouts at the start
-// of a run, where the first kernel of the second stream can be resident before its predecessor is).
-#ifndef CZ_CHAIN_WPE
-#define CZ_CHAIN_WPE 8
-#endif
-#if CZ_CHAIN_WPE > 0
-#define CZ_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(CZ_CHAIN_WPE, CZ_CHAIN_WPE)))
-#else
-#define CZ_CHAIN_ATTR
-#endif
-template <int OPL, int CPL, int NA, int SCHEME>
-__global__ __launch_bounds__(64 * envs_per_wg<CPL>()) CZ_CHAIN_ATTR void k_step_chain(uint32_t *e_state, const int32_t *e_actions, const double *e_lut, int32_t e_N,
-                                                                int32_t e_RW, int32_t e_W, int32_t e_H, int32_t e_D, int32_t e_dyn0,
-                                                                int32_t e_dyn1, uint32_t e_seq, const Params P0) {
-    step_kernel<OPL, CPL, NA, SCHEME, 0, true>(e_state, e_actions, e_lut, e_N, e_RW, e_W, e_H, e_D, e_dyn0, e_dyn1, e_seq, P0);
-}
-
 // reset(): cooking_env.py:178-210 for envs [env_begin, env_begin + count)
 template <int OPL, int CPL, int NA>
 __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin, const int32_t *__restrict__ layout_ids,
@@ -1015,7 +895,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params P, int64_t env_begin,
 
 // observe() only (after cz_set_state)
 template <int OPL, int CPL, int NA>
-__global__ __launch_bounds__(64) void k_observe(const Params P, int64_t env_begin, double *obs_out) {
+__global__ __launch_bounds__(64) void k_observe(const Params P, int64_t env_begin, double *obs_out, uint8_t *codes_out) {
     __shared__ Lds<CPL> lds;
     __shared__ double lut[LUT_SIZE];
     init_lut(P, lut, (int)threadIdx.x, 64);
@@ -1027,7 +907,8 @@ __global__ __launch_bounds__(64) void k_observe(const Params P, int64_t env_begi
     load_env(P, e, cx, P.state + (size_t)(env_begin + i) * P.RW);
     uint32_t dsc[OBS_CHUNK];
     load_desc(P, e.layout, 0, lane, dsc);
-    observe(P, e, cx, lds, lut, dsc, load_submask(P, lane), obs_out + (size_t)i * NA * P.F);
+    observe(P, e, cx, lds, lut, dsc, load_submask(P, lane), obs_out ? obs_out + (size_t)i * NA * P.F : nullptr, true, true,
+            codes_out ? codes_out + (size_t)i * NA * codes_pitch(P.F) : nullptr);
 }
 
 // launchers exported by each instantiation unit
@@ -1036,33 +917,11 @@ struct Launchers {
     // mode: LAUNCH_ONE = one step; LAUNCH_FUSED = P.T steps per launch (actions: P.actions, or the on-device stream when null)
     hipError_t (*step)(const Params &, hipStream_t, int mode);
     hipError_t (*reset)(const Params &, hipStream_t, int64_t, int, const int32_t *, const uint32_t *, const uint32_t *, double *);
-    hipError_t (*observe)(const Params &, hipStream_t, int64_t, int, double *);
-    // how many envs of the overlapped one-step kernel (P.A agents, P.scheme) can be resident on the device at once
-    hipError_t (*resident_envs)(const Params &, int num_cus, int64_t *envs);
+    hipError_t (*observe)(const Params &, hipStream_t, int64_t, int, double *, uint8_t *);
 };
 
 template <int OPL, int CPL>
 struct Inst {
-    template <int NA>
-    static hipError_t resident_na(const Params &P, int num_cus, int64_t *envs) {
-        constexpr int EPW = envs_per_wg<CPL>();
-        int per_cu = 0;
-        hipError_t e = hipSuccess;
-        if constexpr (chain_instance<OPL, CPL, NA>()) {
-            if (P.scheme == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step_chain<OPL, CPL, NA, 3>, 64 * EPW, 0);
-            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_step_chain<OPL, CPL, NA, 1>, 64 * EPW, 0);
-        }
-        *envs = (int64_t)per_cu * num_cus * EPW;          // 0: this instance never overlaps
-        return e;
-    }
-    static hipError_t resident_envs(const Params &P, int num_cus, int64_t *envs) {
-        switch (P.A) {
-        case 1: return resident_na<1>(P, num_cus, envs);
-        case 2: return resident_na<2>(P, num_cus, envs);
-        case 3: return resident_na<3>(P, num_cus, envs);
-        default: return resident_na<4>(P, num_cus, envs);
-        }
-    }
     template <int NA>
     static hipError_t step_na(const Params &P, hipStream_t st, int mode) {
         const bool fused = mode == LAUNCH_FUSED;
@@ -1071,8 +930,6 @@ struct Inst {
         const Early E = early_of(P);
 #define CZ_LAUNCH_STEP(S, F) \
     hipLaunchKernelGGL((k_step<OPL, CPL, NA, S, F>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, P)
-#define CZ_LAUNCH_CHAIN(S) \
-    hipLaunchKernelGGL((k_step_chain<OPL, CPL, NA, S>), grid, block, 0, st, E.state, E.actions, E.lut, E.N, E.RW, E.W, E.H, E.D, E.dyn0_off, E.dyn1_off, E.seq, P)
         if (fused && P.actions) {
             if (P.scheme == 3) CZ_LAUNCH_STEP(3, 2);
             else CZ_LAUNCH_STEP(1, 2);
@@ -1087,13 +944,6 @@ struct Inst {
             else CZ_LAUNCH_STEP(1, 1);
         } else if (!P.actions) {
             return hipErrorInvalidValue;
-        } else if (P.seq & SEQ_PUBLISH) {
-            if constexpr (chain_instance<OPL, CPL, NA>()) {
-                if (P.scheme == 3) CZ_LAUNCH_CHAIN(3);
-                else CZ_LAUNCH_CHAIN(1);
-            } else {
-                return hipErrorInvalidValue;               // (cz_overlap_limit is 0 for this instance: the host never asks)
-            }
         } else if (P.codes) {
             if (P.scheme == 3) CZ_LAUNCH_STEP(3, 3);
             else CZ_LAUNCH_STEP(1, 3);
@@ -1102,7 +952,6 @@ struct Inst {
             else CZ_LAUNCH_STEP(1, 0);
         }
 #undef CZ_LAUNCH_STEP
-#undef CZ_LAUNCH_CHAIN
         return hipGetLastError();
     }
     static hipError_t step(const Params &P, hipStream_t st, int mode) {
@@ -1123,12 +972,12 @@ struct Inst {
         }
         return hipGetLastError();
     }
-    static hipError_t observe(const Params &P, hipStream_t st, int64_t b, int n, double *obs) {
+    static hipError_t observe(const Params &P, hipStream_t st, int64_t b, int n, double *obs, uint8_t *codes) {
         switch (P.A) {
-        case 1: hipLaunchKernelGGL((k_observe<OPL, CPL, 1>), dim3(n), dim3(64), 0, st, P, b, obs); break;
-        case 2: hipLaunchKernelGGL((k_observe<OPL, CPL, 2>), dim3(n), dim3(64), 0, st, P, b, obs); break;
-        case 3: hipLaunchKernelGGL((k_observe<OPL, CPL, 3>), dim3(n), dim3(64), 0, st, P, b, obs); break;
-        default: hipLaunchKernelGGL((k_observe<OPL, CPL, 4>), dim3(n), dim3(64), 0, st, P, b, obs); break;
+        case 1: hipLaunchKernelGGL((k_observe<OPL, CPL, 1>), dim3(n), dim3(64), 0, st, P, b, obs, codes); break;
+        case 2: hipLaunchKernelGGL((k_observe<OPL, CPL, 2>), dim3(n), dim3(64), 0, st, P, b, obs, codes); break;
+        case 3: hipLaunchKernelGGL((k_observe<OPL, CPL, 3>), dim3(n), dim3(64), 0, st, P, b, obs, codes); break;
+        default: hipLaunchKernelGGL((k_observe<OPL, CPL, 4>), dim3(n), dim3(64), 0, st, P, b, obs, codes); break;
         }
         return hipGetLastError();
     }

@@ -468,7 +468,12 @@ class CookingVecEnv:
             ids[e] = L.cz_next_layout_group(self.env_id_base + e, 0, int(pools[e]), len(self.layouts), self._lay_groups, self._lay_active)
         return ids, pools
 
-    def reset(self, layout_ids=None, return_obs=True, env_begin=0, env_count=None):
+    def reset(self, layout_ids=None, return_obs=True, env_begin=0, env_count=None, return_codes=False):
+        """-> the float64 observation [n, A, F] (return_obs), the compact one uint8 [n, A, codes_pitch] (return_codes; then
+        return_obs is ignored), or None"""
+        if return_codes:
+            self.reset(layout_ids, False, env_begin, env_count)
+            return self.observe_compact(env_begin, env_count)
         n = self.num_envs if env_count is None else int(env_count)
         ids, pools = self.initial_layout_ids()
         if layout_ids is not None:
@@ -554,25 +559,24 @@ class CookingVecEnv:
         _native.check(self._h, _native.lib().cz_observe(self._h, env_begin, n, _ptr(obs)))
         return obs
 
+    def observe_compact(self, env_begin=0, env_count=None):
+        """`observe` as one byte per feature: uint8 [n, A, codes_pitch]; `obs_table()[codes[..., :F]]` is the float64 observation"""
+        n = self.num_envs if env_count is None else int(env_count)
+        codes = self._host_array("codes", (n, self.num_agents, self.codes_pitch), np.uint8)
+        _native.check(self._h, _native.lib().cz_observe_compact(self._h, env_begin, n, _ptr(codes)))
+        return codes
+
+    def observe_device(self, d_obs=None, d_codes=None, env_begin=0, env_count=None):
+        """the current observation into device buffers (float64 [n, A, F] and / or codes uint8 [n, A, codes_pitch]), stream-ordered:
+        what a device-resident consumer reads before its first step"""
+        n = self.num_envs if env_count is None else int(env_count)
+        _native.check(self._h, _native.lib().cz_observe_device(self._h, env_begin, n, _dev_ptr(d_obs), _dev_ptr(d_codes)))
+
     # ------------------------------------------------------------------ device-resident API
     def alloc(self, shape, dtype):
         b = DeviceBuffer(self, shape, dtype)
         self._buffers.append(b)
         return b
-
-    def set_overlap(self, enabled=True):
-        """Runs of two or more steps issued through `cz_step_device_ring` may go out as OVERLAPPED launches: consecutive step
-        kernels alternate between two streams and every env's step waits for that env's previous step (a sequence word per
-        env) instead of for the whole previous kernel, which hides the launch boundary (5.2 instead of 6.2 us per step at
-        4096 envs).  Same results.  Off by default; one env per device and process may switch it on (the waiting kernels
-        of two envs together could fill the device), and only batches up to `overlap_limit()` envs ever overlap."""
-        rc = _native.lib().cz_set_overlap(self._h, 1 if enabled else 0)
-        if rc < 0:
-            raise _native.NativeError((_native.lib().cz_last_error(self._h) or b"cz_set_overlap failed").decode())
-        return bool(rc)
-
-    def overlap_limit(self):
-        return int(_native.lib().cz_overlap_limit(self._h))
 
     def set_ring_fused(self, enabled=True):
         """Runs of two or more steps of `step_device_ring` whose action slots are densely packed (`action_stride == num_envs *
@@ -628,7 +632,7 @@ class CookingVecEnv:
         return t
 
     def step_device_ring(self, K, d_ring, action_stride, action_period, first_slot, d_obs, d_rewards, d_term, d_trunc):
-        """K consecutive device-resident steps in one call (cz_step_device_ring: graph replay or overlapped launches); step k
+        """K consecutive device-resident steps in one call (cz_step_device_ring: graph replay, or fused launches after set_ring_fused); step k
         reads its actions from ring slot (first_slot + k) % action_period."""
         p = _dev_ptr
         _native.check(self._h, _native.lib().cz_step_device_ring(self._h, int(K), p(d_ring), int(action_stride), int(action_period),

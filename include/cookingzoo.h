@@ -85,6 +85,14 @@ int cz_sync(cz_handle h);                                  /* wait for the handl
  * policy on: device-pointer steps then need no host synchronisation on either side).  NULL restores the handle's own
  * stream.  The stream must belong to the handle's device and outlive its use here. */
 int cz_set_stream(cz_handle h, void *hip_stream);
+/* STREAM CAPTURE.  While that stream is being captured by the caller (hipStreamBeginCapture, torch.cuda.graph), the
+ * device-pointer calls - cz_step_device, cz_step_device_compact, cz_step_device_many / _ring, cz_rollout*, cz_observe_device,
+ * cz_probe_policy - are pure kernel launches and legal inside the capture: nothing is queried or synchronised (a layout update
+ * staged by cz_update_layouts stays staged until the first call outside the capture; ring runs go out as plain launches).  Replays
+ * of the caller's graph then do exactly what the captured launches did (cooking_env.py:243-288 once per captured step).  Calls
+ * that copy to / from the host or wait (cz_step, cz_reset, cz_get_state, cz_sync, cz_get_stats, cz_update_layouts,
+ * cz_set_layout_group ...) are not; the last two say so, the others fail with HIP's own error.  The captured launches carry the
+ * table pointers of their time: after cz_load_layouts / cz_load_recipes / cz_set_spawn / cz_set_compact_output capture again. */
 
 /* ---- tables ---------------------------------------------------------------------------------------- */
 /* Recipe graphs: replaces RECIPES[name]() / Recipe.node_list (recipe_drawer.py:109-118, recipe.py:29-34).
@@ -123,7 +131,7 @@ int64_t cz_layout_updates(cz_handle h);
 
 /* Agent despawn / respawn (cooking_world.py:267-290 handle_agent_spawn, despawn_agent, respawn_agent; parsing.py:154-167
  * generate_location) for every world of the batch, evaluated by the step kernels themselves - on every path: cz_step,
- * cz_step_device*, overlapped runs, cz_rollout, cz_rollout_actions.  The reference takes its draws from numpy's process-global
+ * cz_step_device*, ring runs, cz_rollout, cz_rollout_actions.  The reference takes its draws from numpy's process-global
  * stream, which defines them for one world per process; here every draw comes from a counter-based stream keyed by (seed,
  * global env id, episode << 32 | t, agent, draw index) (cz_spawn_uniform is the host mirror), so results depend neither on the
  * batch size nor on the sharding nor on the launch form; tests/golden/spawn_keyed_*.npz are trajectories of the unmodified
@@ -159,6 +167,12 @@ int cz_reset(cz_handle h, int64_t env_begin, int64_t env_count, const int32_t *l
 /* observe() (cooking_env.py:271,352-373) of the current state of envs [env_begin, env_begin+env_count):
  * host buffer [env_count][A][F] float64. */
 int cz_observe(cz_handle h, int64_t env_begin, int64_t env_count, double *obs);
+/* ... the same observation in its compact form (see cz_step_device_compact): host buffer uint8 [env_count][A][cz_codes_pitch]. */
+int cz_observe_compact(cz_handle h, int64_t env_begin, int64_t env_count, uint8_t *codes);
+/* ... and into DEVICE buffers, float64 rows [env_count][A][F] and / or codes [env_count][A][cz_codes_pitch] (either may be NULL):
+ * the first observation of a consumer that stays on the device, after cz_reset / cz_set_state.  Stream-ordered, nothing is
+ * synchronised. */
+int cz_observe_device(cz_handle h, int64_t env_begin, int64_t env_count, double *d_obs, uint8_t *d_codes);
 
 /* ---- step ------------------------------------------------------------------------------------------ */
 /* One batched env step = accumulated_step (cooking_env.py:243-269): world_step (cooking_world.py:104-112),
@@ -219,8 +233,8 @@ int cz_ring_prepare(cz_handle h, int32_t K, const int32_t *d_ring, int64_t actio
  * (cut where the ring wraps): cz_rollout_actions' kernel over the ring's own rows, the env state in registers across the
  * steps, every step's observation / rewards / flags written IN PLACE to the [N][A]... buffers of the call.  Afterwards state,
  * output buffers and statistics are bit for bit what K one-step launches leave (cooking_env.py:243-269 K times) - at the cost
- * per step of a fused rollout, without launch boundaries, second streams or sequence words.  Open loop by nature (the actions
- * of the whole run are read by one launch).  Takes precedence over cz_set_overlap; runs with other strides, a compact
+ * per step of a fused rollout, without launch boundaries.  Open loop by nature (the actions
+ * of the whole run are read by one launch).  Runs with other strides, a compact
  * output (cz_set_compact_output) or kernel timing switched on are issued as before.  Returns the previous setting, -1 for a
  * null handle; cz_ring_fused_steps: env steps issued this way so far (reset != 0: zero the count after reading). */
 int cz_set_ring_fused(cz_handle h, int32_t enabled);
@@ -229,34 +243,6 @@ int64_t cz_ring_fused_steps(cz_handle h, int32_t reset);
 /* How many step kernels cz_step_device_ring has replayed from graphs / launched directly on this handle so far
  * (reset != 0: zero both after reading).  bench.py describes its run from these numbers. */
 int cz_launch_counts(cz_handle h, int64_t *graph_kernels, int64_t *direct_kernels, int32_t reset);
-
-/* OVERLAPPED LAUNCHES (opt-in).  With cz_set_overlap(h, 1), runs of two or more steps of cz_step_device_ring / _many go out with
- * consecutive step kernels alternating between the handle's stream and an internal one; every env's step waits for that
- * env's previous step (a sequence word per env, device-scope loads and write-through stores) instead of for the whole
- * previous kernel, so the launch boundary hides behind the neighbouring kernel's work (5.2 instead of 6.2 us per step at
- * 4096 envs).  Same results, same order per env; the first and the last launch of a run are on the handle's stream, so
- * later work on it (or cz_sync) sees the whole run.
- *   - Only batches of at most cz_overlap_limit(h) envs overlap (two of these kernels must be resident in full at the
- *     same time, or waiting waves could hold the slots their predecessors need: half of the envs the device holds of
- *     this kernel, counted for an otherwise idle device - kernels of the caller that hold compute units for long while a
- *     run is in flight take that room away; 4096 envs for the 7x7 levels on an MI355X), only while the observation
- *     stores are write-through (up to 128 MiB of observations per step), and never inside a stream capture of the caller.  Everything else is replayed from graphs as before.
- *   - One handle per device and process may have it switched on (cz_set_overlap returns -1 for a second one): the
- *     waiting kernels of two handles together could fill the device.  CZ_CHAIN=1 switches it on at cz_create.
- *   - A hand-off that does not arrive within two seconds marks the handle instead of hanging: from then on EVERY call that
- *     launches, synchronises or reads results fails (cz_sync, cz_step_device*, cz_rollout, cz_get_state, cz_get_stats,
- *     cz_stats_allgather, cz_memcpy_d2h, cz_timer_stop, ...), because the env states are void.  Recovery: give every env a
- *     new state - cz_set_state or cz_reset over the whole range [0, num_envs) - which clears the mark.
- *   - This is an OPEN-LOOP mode: the launches of a run need their actions before the run starts, and every launch of a
- *     run overwrites the same output buffers (only the last step's outputs can be read).  A closed loop (observation ->
- *     policy -> action) uses cz_step_device; open-loop work that wants every step's outputs uses cz_rollout.
- *   - Only the small kernel instance (at most 64 object slots and 64 cells: every shipped level) overlaps; for the larger
- *     instances cz_overlap_limit is 0.
- * cz_set_overlap returns the previous setting (0 / 1) or -1; cz_chain_counts reports how many kernels went out
- * overlapped (reset != 0: zero after reading). */
-int cz_set_overlap(cz_handle h, int32_t enabled);
-int64_t cz_overlap_limit(cz_handle h);
-int cz_chain_counts(cz_handle h, int64_t *chained_kernels, int32_t reset);
 
 /* T fused steps in one launch with on-device uniform random actions (counter-based stream keyed by
  * (seed, global env id, agent, step0 + t)); state stays in registers between steps.  d_obs, if not NULL,
@@ -311,10 +297,10 @@ int cz_probe_closed_loop(cz_handle h, int32_t K, int32_t reps, int32_t *d_action
  * four features as table indices - it takes the same actions as cz_probe_closed_loop's. */
 int cz_probe_closed_loop_compact(cz_handle h, int32_t K, int32_t reps, int32_t *d_actions, uint8_t *d_codes, double *d_rewards,
                                  uint8_t *d_terminations, uint8_t *d_truncations, float *us_per_step);
-/* test aid: `workgroups` workgroups of a foreign kernel (512 threads and 34 KB of LDS each, like the step kernel's) hold
- * their slots for `microseconds` on a stream of their own; returns at once.  Stands in for a caller's own long-running
- * kernels next to an overlapped run. */
-int cz_probe_occupy(cz_handle h, int32_t workgroups, int32_t microseconds);
+/* test / measurement aid: one launch, on the handle's stream, of the stand-in policy those loops use - d_actions[env][agent] = a
+ * hash of four features of the observation in d_obs (float64 rows) or, with d_obs NULL, in d_codes (compact rows; the same
+ * actions).  tests/test_gpu_capture.py captures [cz_probe_policy, cz_step_device] into a graph of the caller with it. */
+int cz_probe_policy(cz_handle h, const double *d_obs, const uint8_t *d_codes, int32_t *d_actions);
 
 /* ---- statistics + multi-GPU ------------------------------------------------------------------------- */
 int cz_get_stats(cz_handle h, cz_stats *out);              /* device reduction over this handle's envs */

@@ -1,0 +1,153 @@
+"""GPU: the device-pointer step inside a stream capture of the CALLER (raw HIP through ctypes here, torch.cuda.graph in
+test_gpu_zz_torch_interop.py): [policy kernel -> cz_step_device] captured once on the stream given to cz_set_stream, replayed many
+times, must leave state and outputs bit for bit what the same launches leave when issued eagerly - also while a layout update is
+staged (cz_update_layouts' copy is deferred, never issued from inside the capture).  Reference semantics of every captured step:
+cooking_env.py:243-288."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+from cooking_zoo_amd import _native
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+class Hip:
+    """the few HIP calls a caller's graph needs, from the runtime the step library itself uses"""
+
+    def __init__(self):
+        rccl, hip = C.create_string_buffer(512), C.create_string_buffer(512)
+        _native.lib().cz_runtime_paths(rccl, hip, 512)
+        self.lib = C.CDLL(hip.value.decode())
+        for name in ("hipStreamCreateWithFlags", "hipStreamBeginCapture", "hipStreamEndCapture", "hipGraphInstantiate", "hipGraphLaunch",
+                     "hipStreamSynchronize", "hipGraphExecDestroy", "hipGraphDestroy", "hipStreamDestroy", "hipEventCreate", "hipEventRecord",
+                     "hipEventSynchronize", "hipEventElapsedTime", "hipEventDestroy"):
+            getattr(self.lib, name).restype = C.c_int
+
+    def ck(self, rc, what):
+        assert rc == 0, f"{what} failed with HIP error {rc}"
+
+
+def make(n, **kw):
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    args = dict(action_scheme="scheme3", num_layouts=8, auto_reset=True)
+    args.update(kw)
+    return CookingVecEnv(n, "coop_test", "example", 2, 25, ["TomatoLettuceSalad", "CarrotBanana"], **args)
+
+
+def buffers(env):
+    n, A = env.num_envs, env.num_agents
+    return dict(act=env.alloc((n, A), np.int32), obs=env.alloc((n, A, env.F), np.float64), rew=env.alloc((n, A), np.float64),
+                term=env.alloc((n, A), np.uint8), trunc=env.alloc((n, A), np.uint8), codes=env.alloc((n, A, env.codes_pitch), np.uint8))
+
+
+def closed_loop_eager(env, b, steps, compact):
+    L, h = _native.lib(), env._h
+    for _ in range(steps):
+        _native.check(h, L.cz_probe_policy(h, None if compact else b["obs"].ptr, b["codes"].ptr if compact else None, b["act"].ptr))
+        if compact:
+            env.step_device_compact(b["act"], b["codes"], b["rew"], b["term"], b["trunc"])
+        else:
+            env.step_device(b["act"], b["obs"], b["rew"], b["term"], b["trunc"])
+
+
+@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("mode", [0, 1, 2])                       # hipStreamCaptureModeGlobal / ThreadLocal / Relaxed
+def test_step_captured_into_a_callers_graph_replays_bit_exact(compact, mode):
+    hip = Hip()
+    n, K, R = 1024, 8, 200
+    env, ref = make(n), make(n)
+    be, br = buffers(env), buffers(ref)
+    stream = C.c_void_p()
+    hip.ck(hip.lib.hipStreamCreateWithFlags(C.byref(stream), 1), "hipStreamCreateWithFlags")
+    for e, b in ((env, be), (ref, br)):
+        e.reset(return_obs=False)
+        e.observe_device(b["obs"], b["codes"])                        # the first observation, on the device, in both forms
+    env.set_stream(stream)
+    # a staged layout update at capture time: the pool cut in two, the inactive half rewritten while a long rollout still runs -
+    # cz_update_layouts cannot copy yet, and the captured steps must not try to (hipEventQuery / copies invalidate a capture)
+    for e in (env, ref):
+        e.set_layout_group(2, 0)
+    env.rollout(1500, 7, 0); ref.rollout(1500, 7, 0)
+    fresh = env.layouts[4:8][::-1]
+    env.update_layouts(4, fresh); ref.update_layouts(4, fresh)
+    L, h = _native.lib(), env._h
+    graph, gexec = C.c_void_p(), C.c_void_p()
+    hip.ck(hip.lib.hipStreamBeginCapture(stream, mode), "hipStreamBeginCapture")
+    closed_loop_eager(env, be, K, compact)                             # K x [policy, step]: captured, not executed
+    hip.ck(hip.lib.hipStreamEndCapture(stream, C.byref(graph)), "hipStreamEndCapture (a call inside the capture invalidated it)")
+    hip.ck(hip.lib.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0)), "hipGraphInstantiate")
+    t_before = env.get_state()[:, 0].copy()                            # (outside the capture: also flushes the staged update)
+    for _ in range(R):
+        hip.ck(hip.lib.hipGraphLaunch(gexec, stream), "hipGraphLaunch")
+    hip.ck(hip.lib.hipStreamSynchronize(stream), "hipStreamSynchronize")
+    ref.sync()
+    assert np.array_equal(t_before, ref.get_state()[:, 0]), "capturing must not have stepped anything"
+    closed_loop_eager(ref, br, K * R, compact)
+    ref.sync()
+    assert np.array_equal(env.get_state(), ref.get_state())
+    for k in ("act", "rew", "term", "trunc") + (("codes",) if compact else ("obs",)):
+        assert np.array_equal(be[k].to_host().view(np.uint8), br[k].to_host().view(np.uint8)), k
+    assert env.stats() == ref.stats() and env.stats()["episodes"] > n
+    # the replayed closed loop, timed: one graph launch = K x (policy + step)
+    ev0, ev1 = C.c_void_p(), C.c_void_p()
+    hip.lib.hipEventCreate(C.byref(ev0)); hip.lib.hipEventCreate(C.byref(ev1))
+    hip.lib.hipEventRecord(ev0, stream)
+    for _ in range(R):
+        hip.lib.hipGraphLaunch(gexec, stream)
+    hip.lib.hipEventRecord(ev1, stream)
+    hip.ck(hip.lib.hipEventSynchronize(ev1), "hipEventSynchronize")
+    ms = C.c_float()
+    hip.lib.hipEventElapsedTime(C.byref(ms), ev0, ev1)
+    print(f"\nreplayed closed loop in the caller's graph ({'codes' if compact else 'float64'}, {n} envs, capture mode {mode}): "
+          f"{ms.value * 1e3 / (K * R):.2f} us per step")
+    hip.lib.hipEventDestroy(ev0); hip.lib.hipEventDestroy(ev1)
+    hip.lib.hipGraphExecDestroy(gexec); hip.lib.hipGraphDestroy(graph)
+    env.set_stream(None)
+    hip.lib.hipStreamDestroy(stream)
+    env.close(); ref.close()
+
+
+def test_ring_runs_and_rollouts_inside_a_capture():
+    """cz_step_device_ring inside a caller's capture goes out as plain launches (no nested capture), cz_rollout_actions as its one
+    fused launch; what must not be captured says so"""
+    hip = Hip()
+    n, A, period = 512, 2, 8
+    env, ref = make(n), make(n)
+    be, br = buffers(env), buffers(ref)
+    ring = np.random.default_rng(2).integers(0, 5, size=(period, n, A), dtype=np.int32)
+    de, dr = env.alloc((period, n, A), np.int32), ref.alloc((period, n, A), np.int32)
+    de.from_host(ring); dr.from_host(ring)
+    env.reset(return_obs=False); ref.reset(return_obs=False)
+    stream = C.c_void_p()
+    hip.ck(hip.lib.hipStreamCreateWithFlags(C.byref(stream), 1), "hipStreamCreateWithFlags")
+    env.set_stream(stream)
+    _native.check(env._h, _native.lib().cz_update_layouts(env._h, 0, 0, None, None))   # (count 0: creates the copy stream, outside the capture)
+    graph, gexec = C.c_void_p(), C.c_void_p()
+    hip.ck(hip.lib.hipStreamBeginCapture(stream, 0), "hipStreamBeginCapture")
+    env.step_device_ring(12, de, n * A, period, 3, be["obs"], be["rew"], be["term"], be["trunc"])
+    env.rollout_actions(de, period, None, None, None, None)
+    with pytest.raises(_native.NativeError, match="not inside a stream capture"):
+        env.set_layout_group(2, 1)
+    with pytest.raises(_native.NativeError, match="not inside a stream capture"):
+        env.update_layouts(0, env.layouts[:2])
+    hip.ck(hip.lib.hipStreamEndCapture(stream, C.byref(graph)), "hipStreamEndCapture")
+    hip.ck(hip.lib.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0)), "hipGraphInstantiate")
+    for _ in range(5):
+        hip.ck(hip.lib.hipGraphLaunch(gexec, stream), "hipGraphLaunch")
+        ref.step_device_ring(12, dr, n * A, period, 3, br["obs"], br["rew"], br["term"], br["trunc"])
+        ref.rollout_actions(dr, period, None, None, None, None)
+    hip.ck(hip.lib.hipStreamSynchronize(stream), "hipStreamSynchronize")
+    ref.sync()
+    assert np.array_equal(env.get_state(), ref.get_state())
+    assert np.array_equal(bits(be["obs"].to_host()), bits(br["obs"].to_host()))
+    hip.lib.hipGraphExecDestroy(gexec); hip.lib.hipGraphDestroy(graph)
+    env.set_stream(None)
+    hip.lib.hipStreamDestroy(stream)
+    env.close(); ref.close()

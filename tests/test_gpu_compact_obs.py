@@ -179,7 +179,7 @@ def test_fused_rollout_with_a_compact_trajectory(scheme, level, agents, recipes,
 
 
 def test_ring_runs_with_compact_output_set_on_the_handle():
-    """cz_set_compact_output: ring runs (graph replay; never overlapped) write the codes too; switching it off restores the plain
+    """cz_set_compact_output: ring runs (graph replay) write the codes too; switching it off restores the plain
     kernels, and the graphs captured before the switch are not replayed with a stale pointer"""
     from oracle_binding import VecOracle
     n, A, period, K = 192, 2, 8, 20
@@ -187,7 +187,6 @@ def test_ring_runs_with_compact_output_set_on_the_handle():
     orc = VecOracle.from_vec_env(env)
     env.reset(return_obs=False)
     orc.reset()
-    env.set_overlap(True)                                   # (must not be used for launches that write codes)
     table = env.obs_table()
     rng = np.random.default_rng(9)
     ring_host = rng.integers(0, 5, size=(period, n, A), dtype=np.int32)

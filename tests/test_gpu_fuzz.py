@@ -148,9 +148,8 @@ def run_case(i, kw, seed, extra):
         assert np.array_equal(bits(o), bits(oo)) and np.array_equal(bits(r), bits(ro)), (ctx, t)
         assert np.array_equal(te, to) and np.array_equal(tr, uo), (ctx, t)
     assert np.array_equal(strip(env.get_state()), orc.records), ctx
-    # ... and a run of overlapped launches (cz_step_device_ring: the third kernel variant, ordered per env by sequence words)
+    # ... and a ring run replayed from graphs (cz_step_device_ring)
     from cooking_zoo_amd import _native
-    env.set_overlap(True)
     K, period = int(rng.integers(2, 40)), int(rng.integers(2, 12))
     first = int(rng.integers(period))
     ring_host = rng.integers(0, n_act, size=(period, n, A), dtype=np.int32)

@@ -88,7 +88,7 @@ def test_all_store_flavours_match_oracle(wt, level, meta, agents, recipes, schem
 
 
 def _ring_run_vs_oracle(env, orc, K, period, rng, first_slot=0):
-    """K steps through cz_step_device_ring (overlapped launches when the batch qualifies) against the oracle: what the last
+    """K steps through cz_step_device_ring (graph replay / direct launches) against the oracle: what the last
     step left in the output buffers, the records, the episode statistics."""
     import ctypes as C
     from cooking_zoo_amd import _native
@@ -114,65 +114,47 @@ def _ring_run_vs_oracle(env, orc, K, period, rng, first_slot=0):
 
 
 @pytest.mark.parametrize("level,meta,agents,recipes,scheme", FAMILIES)
-def test_overlapped_runs_match_oracle(level, meta, agents, recipes, scheme):
-    """Runs of cz_step_device_ring go out as overlapped launches (two streams alternately, a sequence word per env instead
-    of the launch boundary): same results as stepping the oracle one step at a time, for every level family, with
-    episodes ending and restarting inside the runs; and the library says that it did overlap."""
+def test_ring_runs_match_oracle(level, meta, agents, recipes, scheme):
+    """Runs of cz_step_device_ring (captured into HIP graphs on first use, replayed afterwards; short pieces launched directly):
+    same results as stepping the oracle one step at a time, for every level family, with episodes ending and restarting
+    inside the runs; and the library says how the launches went out."""
     import ctypes as C
     from cooking_zoo_amd import _native
     from oracle_binding import VecOracle
     env = make(200, level, meta, agents, recipes, scheme, max_steps=17, num_layouts=6)
-    env.set_overlap(True)
     orc = VecOracle.from_vec_env(env)
     assert np.array_equal(bits(env.reset()), bits(orc.reset()))
     rng = np.random.default_rng(5)
     L = _native.lib()
-    L.cz_chain_counts(env._h, None, 1)
+    L.cz_launch_counts(env._h, None, None, 1)
     for K, period, first in ((2, 8, 0), (37, 16, 5), (3, 3, 2), (60, 64, 63)):
         _ring_run_vs_oracle(env, orc, K, period, rng, first)
-    c = C.c_int64()
-    L.cz_chain_counts(env._h, C.byref(c), 0)
-    # (only the small kernel instance - one slot and one cell per lane, every shipped level - with up to three agents overlaps
-    # its launches; everything else reports an overlap limit of 0 and replays graphs)
-    assert c.value == (2 + 37 + 3 + 60 if env.overlap_limit() >= 200 else 0)
-    assert (env.overlap_limit() > 0) == (env.dims.D <= 64 and env.dims.C <= 64 and agents <= 3)
+    g, d = C.c_int64(), C.c_int64()
+    L.cz_launch_counts(env._h, C.byref(g), C.byref(d), 0)
+    assert g.value + d.value == 2 + 37 + 3 + 60 and g.value > 0
     st = env.stats()
     assert st["episodes"] == int(orc.records[:, soa.W_EPISODE].sum()) + int((orc.records[:, soa.W_STATUS] & 1).sum())
     env.close()
 
 
-@pytest.mark.parametrize("n,overlaps", [(4096, True), (16384, False)])
-def test_long_ring_runs_at_and_above_the_overlap_limit(n, overlaps):
-    """300-step runs of the config-2 workload.  4096 envs: two step kernels are resident in full at the same time, so the
-    run goes out as overlapped launches.  16 384 envs: waiting waves could hold the slots their predecessors still need,
-    so the library must not overlap (it replays graphs) - and says so."""
-    import ctypes as C
-    from cooking_zoo_amd import _native
+@pytest.mark.parametrize("n", [4096, 16384])
+def test_long_ring_runs(n):
+    """300-step runs of the config-2 workload through cz_step_device_ring"""
     from oracle_binding import ShardedOracle
     env = make(n, "coop_test", "example", 2, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3", max_steps=40, num_layouts=64)
-    env.set_overlap(True)
     orc = ShardedOracle(env)
     assert np.array_equal(bits(env.reset()), bits(orc.reset()))
-    L = _native.lib()
-    assert (n <= L.cz_overlap_limit(env._h)) == overlaps
-    L.cz_chain_counts(env._h, None, 1)
     _ring_run_vs_oracle(env, orc, 300, 32, np.random.default_rng(77))
-    c = C.c_int64()
-    L.cz_chain_counts(env._h, C.byref(c), 0)
-    assert c.value == (300 if overlaps else 0)
     env.close()
 
 
-def test_many_short_overlapped_runs_at_the_limit():
-    """the start of a run is where the first kernel of the second stream can be resident before its predecessor is: 80
-    runs of 2-40 steps at the overlap limit (the two kernels in flight fill the device), mostly without synchronising
-    in between (tools/overlap_stress.py is the long version)"""
+def test_many_short_ring_runs():
+    """80 runs of 2-40 steps from random slots, mostly without synchronising in between (graph cache churn: at most 64 graphs are
+    kept per handle)"""
     from cooking_zoo_amd import _native
     from oracle_binding import ShardedOracle
     n, A, period = 4096, 2, 32
     env = make(n, "coop_test", "example", A, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3", max_steps=40, num_layouts=64)
-    env.set_overlap(True)
-    assert n <= env.overlap_limit()
     orc = ShardedOracle(env)
     assert np.array_equal(bits(env.reset()), bits(orc.reset()))
     L = _native.lib()
@@ -195,79 +177,13 @@ def test_many_short_overlapped_runs_at_the_limit():
     env.close()
 
 
-@pytest.mark.parametrize("hold_ms", [30, 2600])
-def test_overlapped_run_next_to_a_foreign_kernel(hold_ms):
-    """An overlapped run counts on the device for itself (two step kernels resident in full).  Here a foreign kernel of the
-    caller holds half of the workgroup slots while a 4096-env run is in flight - for 30 ms (the run can only be delayed) and
-    for 2.6 s (longer than the hand-off deadline of two seconds).  One of the two documented outcomes must hold: the run
-    completes bit-exact, or the library reports that a launch gave up waiting - on EVERY entry point, not only cz_sync -
-    and replacing all env states (cz_set_state from a snapshot) makes the handle usable again, after which the same run,
-    undisturbed, is bit-exact."""
-    from cooking_zoo_amd import _native
-    from oracle_binding import ShardedOracle
-    n, A, period, K = 4096, 2, 32, 120
-    env = make(n, "coop_test", "example", A, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3", max_steps=40, num_layouts=64)
-    env.set_overlap(True)
-    assert n <= env.overlap_limit()
-    orc = ShardedOracle(env)
-    assert np.array_equal(bits(env.reset()), bits(orc.reset()))
-    L = _native.lib()
-    rng = np.random.default_rng(21)
-    ring_host = rng.integers(0, env.n_actions, size=(period, n, A), dtype=np.int32)
-    d_ring = env.alloc((period, n, A), np.int32)
-    d_ring.from_host(ring_host)
-    d_obs, d_rew = env.alloc((n, A, env.F), np.float64), env.alloc((n, A), np.float64)
-    d_t, d_u = env.alloc((n, A), np.uint8), env.alloc((n, A), np.uint8)
-    outs = (d_obs.ptr, d_rew.ptr, d_t.ptr, d_u.ptr)
-    snapshot = env.get_state()
-    for k in range(K):
-        oo, ro, to, uo = orc.step(ring_host[k % period], k == K - 1)
-    # half of the device's workgroup slots (256 CUs x 4 workgroups of this shape), held by somebody else's kernel
-    _native.check(env._h, L.cz_probe_occupy(env._h, 512, hold_ms * 1000))
-    _native.check(env._h, L.cz_step_device_ring(env._h, K, d_ring.ptr, n * A, period, 0, *outs))
-    abandoned = False
-    try:
-        env.sync()
-    except _native.NativeError as exc:
-        abandoned = True
-        assert "gave up waiting" in str(exc)
-    if abandoned:
-        assert hold_ms > 2000, "a 30 ms guest must not make a hand-off time out"
-        for call in (env.get_state, env.stats, d_rew.to_host):             # sticky: results are void everywhere
-            with pytest.raises(_native.NativeError, match="gave up waiting"):
-                call()
-        with pytest.raises(_native.NativeError, match="gave up waiting"):
-            _native.check(env._h, L.cz_step_device_ring(env._h, 2, d_ring.ptr, n * A, period, 0, *outs))
-        import time
-        time.sleep(max(0.0, hold_ms / 1000.0 - 2.0) + 0.3)                  # let the guest leave
-        env.set_state(snapshot)                                             # the documented recovery: every env gets a new state
-        _native.check(env._h, L.cz_step_device_ring(env._h, K, d_ring.ptr, n * A, period, 0, *outs))
-        env.sync()
-    assert np.array_equal(strip(env.get_state()), orc.records)
-    assert np.array_equal(bits(d_obs.to_host()), bits(oo)) and np.array_equal(bits(d_rew.to_host()), bits(ro))
-    assert np.array_equal(d_t.to_host(), to) and np.array_equal(d_u.to_host(), uo)
-    env.close()
-
-
-def test_overlap_is_opt_in_and_one_handle_per_device():
-    import ctypes as C
+def test_step_device_many_matches_oracle():
     from cooking_zoo_amd import _native
     from oracle_binding import VecOracle
     a = make(64, "coop_test", "example", 2, ["TomatoLettuceSalad", "CarrotBanana"])
-    b = make(64, "coop_test", "example", 2, ["TomatoLettuceSalad", "CarrotBanana"])
     orc = VecOracle.from_vec_env(a)
     assert np.array_equal(bits(a.reset()), bits(orc.reset()))
-    L, c = _native.lib(), C.c_int64()
-    _ring_run_vs_oracle(a, orc, 10, 4, np.random.default_rng(1))           # off by default: graph replay
-    L.cz_chain_counts(a._h, C.byref(c), 1)
-    assert c.value == 0
-    assert a.set_overlap(True) is False and a.set_overlap(True) is True      # returns the previous setting
-    with pytest.raises(_native.NativeError, match="another handle"):
-        b.set_overlap(True)
-    _ring_run_vs_oracle(a, orc, 10, 4, np.random.default_rng(2))
-    L.cz_chain_counts(a._h, C.byref(c), 1)
-    assert c.value == 10
-    # cz_step_device_many overlaps the same way
+    L = _native.lib()
     rng = np.random.default_rng(3)
     acts = rng.integers(0, a.n_actions, size=(6, 64, 2), dtype=np.int32)
     d_acts, d_obs = a.alloc(acts.shape, np.int32), a.alloc((64, 2, a.F), np.float64)
@@ -278,11 +194,7 @@ def test_overlap_is_opt_in_and_one_handle_per_device():
     for k in range(6):
         oo, ro, to, uo = orc.step(acts[k])
     assert np.array_equal(bits(d_obs.to_host()), bits(oo)) and np.array_equal(strip(a.get_state()), orc.records)
-    L.cz_chain_counts(a._h, C.byref(c), 1)
-    assert c.value == 6
-    a.close()                                                                 # releases the right
-    assert b.set_overlap(True) is False
-    b.close()
+    a.close()
 
 
 def _full_size_case(env, steps, T_fused, seed):

@@ -156,28 +156,27 @@ def test_ring_fused_config2_full_size():
         assert all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(a, b))
 
 
-def test_ring_fused_takes_precedence_over_overlap():
-    """with both switches on, a fusable run goes out fused (no overlapped launches); a run that cannot be fused still overlaps"""
+def test_runs_that_cannot_be_fused_are_replayed_from_graphs():
+    """with the switch on, a fusable run goes out fused; a run whose slots are not densely packed is issued as before"""
     import ctypes as C
     n, A, period = 256, 2, 8
     env = make(n, "coop_test", "example", A, ["TomatoLettuceSalad", "CarrotBanana"], "scheme3")
     env.reset(return_obs=False)
     L, h = _native.lib(), env._h
-    env.set_overlap(True)
     env.set_ring_fused(True)
     rng = np.random.default_rng(4)
     dense = env.alloc((period, n, A), np.int32); dense.from_host(rng.integers(0, 5, size=(period, n, A), dtype=np.int32))
     padded = env.alloc((period, n + 2, A), np.int32); padded.from_host(rng.integers(0, 5, size=(period, n + 2, A), dtype=np.int32))
     d_obs, d_rew = env.alloc((n, A, env.F), np.float64), env.alloc((n, A), np.float64)
     d_t, d_u = env.alloc((n, A), np.uint8), env.alloc((n, A), np.uint8)
-    chained = C.c_int64()
-    _native.check(h, L.cz_chain_counts(h, C.byref(chained), 1))
+    g, d = C.c_int64(), C.c_int64()
+    _native.check(h, L.cz_launch_counts(h, C.byref(g), C.byref(d), 1))
     env.step_device_ring(20, dense, n * A, period, 0, d_obs, d_rew, d_t, d_u)
     env.sync()
-    _native.check(h, L.cz_chain_counts(h, C.byref(chained), 1))
-    assert env.ring_fused_steps(reset=True) == 20 and chained.value == 0
+    _native.check(h, L.cz_launch_counts(h, C.byref(g), C.byref(d), 1))
+    assert env.ring_fused_steps(reset=True) == 20 and g.value + d.value == 0
     env.step_device_ring(20, padded, (n + 2) * A, period, 0, d_obs, d_rew, d_t, d_u)
     env.sync()
-    _native.check(h, L.cz_chain_counts(h, C.byref(chained), 1))
-    assert env.ring_fused_steps() == 0 and chained.value == 20
+    _native.check(h, L.cz_launch_counts(h, C.byref(g), C.byref(d), 1))
+    assert env.ring_fused_steps() == 0 and g.value + d.value == 20
     env.close()

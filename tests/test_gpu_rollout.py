@@ -285,17 +285,14 @@ def test_fused_trajectory_with_many_descriptor_chunks():
     env.close()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_ring_api_with_graph_replay_matches_direct_launches(overlap):
-    """cz_step_device_ring (runs captured into HIP graphs and replayed on later calls, or - `overlap` - sent out as
-    overlapped launches ordered per env) against cz_step_device_many on a twin env: odd start slots, wrap-around, K
-    below / across / far above the segment size."""
+def test_ring_api_with_graph_replay_matches_direct_launches():
+    """cz_step_device_ring (runs captured into HIP graphs and replayed on later calls) against cz_step_device_many on a
+    twin env: odd start slots, wrap-around, K below / across / far above the segment size."""
     import ctypes as C
     from cooking_zoo_amd import _native
     n, A, period = 256, 2, 64
     kw = dict(max_steps=37, num_layouts=8)
     env, ref = make(n, **kw), make(n, **kw)
-    env.set_overlap(overlap)
     L = _native.lib()
     rng = np.random.default_rng(3)
     ring = rng.integers(0, 5, size=(period, n, A), dtype=np.int32)

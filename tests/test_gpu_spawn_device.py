@@ -1,6 +1,6 @@
 """Agent despawn / respawn evaluated by the step kernels (cz_set_spawn, Ops::handle_agent_spawn) against the host model
 (cooking_zoo_amd/spawn.py SpawnBook, and the scalar transliteration of the reference's rule in test_spawn_book.py) on top of
-the oracle: every stepping path - cz_step, cz_step_device, overlapped ring runs, cz_rollout - and shard invariance; and
+the oracle: every stepping path - cz_step, cz_step_device, ring runs, cz_rollout - and shard invariance; and
 against the oracle's own restatement of the rule (pinned to the reference by tests/golden/spawn_keyed_*.npz) on mixed-level
 batches (spawn areas per level) and on every kernel instance."""
 import ctypes as C
@@ -157,10 +157,9 @@ def test_rollout_matches_the_scalar_rule_and_is_shard_invariant():
     [p.close() for p in parts]
 
 
-def test_overlapped_ring_runs_do_the_same_bookkeeping():
+def test_ring_runs_do_the_same_bookkeeping():
     n, A, period, K = 256, 4, 16, 48
     env, ref = make(n, max_steps=25), make(n, max_steps=25)
-    env.set_overlap(True)
     env.reset(return_obs=False)
     ref.reset(return_obs=False)
     rng = np.random.default_rng(3)

@@ -83,5 +83,32 @@ def test_torch_tensors_on_the_callers_stream():
     assert np.array_equal(bits(decoded.cpu().numpy()), bits(o))
     with pytest.raises(ValueError):
         env.step_device(acts_log[0].t(), obs, rew, term, trunc)                                  # not contiguous
+    # ---- torch.cuda.graph: [a torch policy -> cz_step_device] captured once (torch's default capture mode is "global", the
+    # strictest), replayed 200 times; the closed loop must do what the same loop does eagerly on the twin env
+    def policy(o):
+        return torch.remainder(o.view(torch.int64)[:, :, :8].sum(-1), 5).to(torch.int32)
+    cap = torch.cuda.Stream(device=dev)
+    act = torch.zeros((n, A), dtype=torch.int32, device=dev)
+    env.sync()
+    env.observe_device(obs)
+    torch.cuda.synchronize()
+    env.set_stream(cap)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=cap):
+        for _ in range(4):
+            act.copy_(policy(obs))
+            env.step_device(act, obs, rew, term, trunc)
+    R = 200
+    for _ in range(R):
+        graph.replay()
+    torch.cuda.synchronize()
+    o = ref.observe()
+    for _ in range(4 * R):
+        a = np.remainder(o.view(np.int64)[:, :, :8].sum(-1), 5).astype(np.int32)
+        o, r, te, tr = ref.step(a)
+    assert np.array_equal(act.cpu().numpy(), a)
+    assert np.array_equal(bits(obs.cpu().numpy()), bits(o)) and np.array_equal(bits(rew.cpu().numpy()), bits(r))
+    assert np.array_equal(env.get_state(), ref.get_state())
+    env.set_stream(None)
     env.close()
     ref.close()
