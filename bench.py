@@ -15,9 +15,14 @@ No torch anywhere: every rank runs on the system ROCm runtime; the ranks of the 
 (cooking_zoo_amd.distributed.FileRendezvous) and, for the barrier of the timed region and the episode-statistics
 all-gather, through the C-ABI's own RCCL communicator (cz_comm_init / cz_comm_barrier / cz_stats_allgather).
 
+The batch, its shards, the communicator and the statistics exchange are `cooking_zoo_amd.ShardedVecEnv` - the same object a user
+gets; this file only times it.
+
 Timing: W warmup steps, then the K-step region is timed `--repeats` times; every region is bracketed by a stream
 synchronisation + barrier over all ranks on both sides, its time is the MAX over ranks, and `value` / `ms_per_step` are
-the MEDIAN over the regions (min and max are reported next to it).
+the MEDIAN over the regions (min and max are reported next to it).  Every timed launch is the boundary-ordered one-step kernel
+`cz::k_step<1,1,2,3,0>` replayed from HIP graphs: `value`, `roofline.kernel_us` and profiles/r05/kernel_stats.csv describe the same
+launches.
 """
 import argparse
 import ctypes as C
@@ -120,13 +125,51 @@ def pmc_traffic(kernel_key):
     return best
 
 
-def roofline_block(b_alg, units, us_per_launch, kernel, note=None):
-    """algorithmic bytes per env-step x env-steps per launch / launch duration, against the 8 TB/s HBM peak"""
+CU_COUNT, SHADER_GHZ = 256, 2.4           # MI355X_MICROARCH.md: 256 CUs (8 XCDs x 32), 2.4 GHz
+
+
+def issue_counts(instance):
+    """Instructions per env-step of one kernel instance (scalar / vector / LDS), from the committed rocprofv3 --pmc passes of this
+    round or the last one that has them (profiles/rNN/issue_per_env_step.json, tools/collect_r05.sh), or None."""
+    best = None
+    for d in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "issue_per_env_step.json"))):
+        try:
+            t = json.load(open(d))
+            if instance in t:
+                best = dict(t[instance], source=os.path.relpath(d, REPO))
+        except Exception:
+            pass
+    return best
+
+
+def issue_block(instance, env_steps_per_s):
+    """The instruction-issue roof next to the HBM one.  A CU has ONE scalar unit (one SALU instruction per
+    cycle for all its waves) and four SIMDs whose vector ALU takes a wave64 instruction every 4 cycles:
+        salu_util = SALU instructions per env-step x env-steps/s / (256 CUs x 2.4 GHz)
+        valu_util = VALU instructions per env-step x 4 cycles x env-steps/s / (256 CUs x 4 SIMDs x 2.4 GHz)
+    `frac` is the larger of the two: how much of the binding issue port the leg uses."""
+    c = issue_counts(instance)
+    if c is None:
+        return None
+    cap = CU_COUNT * SHADER_GHZ * 1e9
+    salu, valu = c["salu"] * env_steps_per_s / cap, c["valu"] * 4.0 * env_steps_per_s / (cap * 4.0)
+    return {"salu_per_env_step": c["salu"], "valu_per_env_step": c["valu"], "salu_util": salu, "valu_util": valu, "frac": max(salu, valu),
+            "peak": "256 CUs x 2.4 GHz: one scalar instruction per CU and cycle; one wave64 vector instruction per SIMD and 4 cycles",
+            "instance": instance, "counts_from": c["source"]}
+
+
+def roofline_block(b_alg, units, us_per_launch, kernel, note=None, instance=None):
+    """algorithmic bytes per env-step x env-steps per launch / launch duration, against the 8 TB/s HBM peak; with
+    `instance` (a key of issue_per_env_step.json) also the instruction-issue roof, and `bound` names the one that binds."""
     achieved = b_alg * units / (us_per_launch * 1e-6) / 1e9
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
            "kernel": kernel, "kernel_us": us_per_launch, "alg_bytes_per_env_step": b_alg, "units_per_launch": units}
     if note:
         out["kernel_us_from"] = note
+    if instance:
+        out["issue"] = issue_block(instance, units / (us_per_launch * 1e-6))
+        if out["issue"] and out["issue"]["frac"] > out["frac"]:
+            out["bound"] = "issue"
     return out
 
 
@@ -189,8 +232,8 @@ def leg_fused_compact(env, K):
         b_alg = algorithmic_bytes_per_env_step(env) - A * 8 * env.F + A * env.F
         out = {"env_steps_per_s_per_gpu": (env.stats()["env_steps"] - f0) / dt, "steps_per_launch": T, "ms_per_step": dt * 1e3 / (reps * T),
                "api": "cz_rollout_compact: uint8 code trajectory [T][N][A][%d] in HBM (no float64 rows)" % env.codes_pitch}
-        out["roofline"] = roofline_block(b_alg, N, out["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,4> (32 steps per launch, codes)",
-                                         "wall clock around the cz_rollout_compact launches; algorithmic bytes with 1 byte per feature")
+        out["roofline"] = roofline_block(b_alg, N, out["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,5> (32 steps per launch, codes only)",
+                                         "wall clock around the cz_rollout_compact launches; algorithmic bytes with 1 byte per feature", "k_step<1,1,2,3,5>")
         return out
     finally:
         d_codes.free()
@@ -216,7 +259,7 @@ def leg_closed_loop(env, d_obs, d_rew, d_term, d_trunc):
             "what": "closed loop on one stream: cz_step_device -> policy kernel (next actions = hash of the observation just written) "
                     f"-> cz_step_device ...; {K}-step HIP graph replayed {reps} times, HIP events; includes the policy kernel and its launch boundary",
             "roofline": roofline_block(b_alg, N, us.value, "cz::k_step<1,1,2,3,0> + k_probe_policy per step",
-                                       "HIP events around graph replays of the closed loop; step + policy kernel + both boundaries")}
+                                       "HIP events around graph replays of the closed loop; step + policy kernel + both boundaries", "k_step<1,1,2,3,0>")}
 
 
 def leg_closed_loop_compact(env, d_rew, d_term, d_trunc):
@@ -243,8 +286,8 @@ def leg_closed_loop_compact(env, d_rew, d_term, d_trunc):
     return {"env_steps_per_s": stepped * N / (us.value * 1e-6), "us_per_step": us.value, "envs": N, "obs_bytes_per_env_step": A * env.codes_pitch,
             "what": "closed loop on one stream over the compact observation: cz_step_device_compact (uint8 code per feature, table of 256 "
                     f"float64 resident; no float64 rows written) -> policy kernel reading the codes -> ...; {K}-step HIP graph replayed {reps} times",
-            "roofline": roofline_block(b_alg, N, us.value, "cz::k_step<1,1,2,3,0> (codes only) + k_probe_policy_codes per step",
-                                       "HIP events around graph replays; algorithmic bytes with 1 byte per feature")}
+            "roofline": roofline_block(b_alg, N, us.value, "cz::k_step<1,1,2,3,3> (codes only) + k_probe_policy_codes per step",
+                                       "HIP events around graph replays; algorithmic bytes with 1 byte per feature", "k_step<1,1,2,3,3>")}
 
 
 def leg_fused_actions(env, K):
@@ -267,7 +310,7 @@ def leg_fused_actions(env, K):
         out = {"env_steps_per_s_per_gpu": (env.stats()["env_steps"] - f0) / dt, "steps_per_launch": T, "ms_per_step": dt * 1e3 / (reps * T),
                "api": "cz_rollout_actions: int32 actions [T][N][A] of the caller in HBM, obs trajectory [T][N][A][F]"}
         out["roofline"] = roofline_block(algorithmic_bytes_per_env_step(env), N, out["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,2> (32 steps per launch)",
-                                         "wall clock around the cz_rollout_actions launches")
+                                         "wall clock around the cz_rollout_actions launches", "k_step<1,1,2,3,2>")
         return out
     finally:
         d_traj.free()
@@ -299,6 +342,10 @@ def leg_ring_fused(env, K, d_obs, d_rew, d_term, d_trunc):
                 times.append(time.perf_counter() - t0)
             dt = sorted(times)[len(times) // 2]
             out["K=%d" % k] = {"us_per_step": dt * 1e6 / k, "env_steps_per_s": N * k / dt}
+        # (7.1 of the 18.2 MB of rows per step reach HBM, profiles/r04/ring_fused_pmc.txt: the roof that binds is instruction issue)
+        out["roofline"] = roofline_block(algorithmic_bytes_per_env_step(env), N, out["K=2000"]["us_per_step"],
+                                         "cz::k_step<1,1,2,3,2> (fused over the ring's rows, outputs in place)",
+                                         "wall clock of 2000-step regions between synchronisations", "k_step<1,1,2,3,2>/in_place")
         return out
     finally:
         env.set_ring_fused(was)
@@ -375,7 +422,7 @@ def leg_cooking_policy(device_id):
            "return_sum_agent0": st["return_sum"][0],
            "what": f"one launch per step, launch-boundary ordering (graph replay); every env replays the reference heuristic agent's actions "
                    f"(golden fixtures cfg2_coop_2agents: {P} episodes of {min(T)}-{max(T)} steps that chop, plate and deliver) from its own phase",
-           "roofline": roofline_block(b_alg, N, us, "cz::k_step<1,1,2,3,0>", "HIP events around one graph-replayed run of 512 launches")}
+           "roofline": roofline_block(b_alg, N, us, "cz::k_step<1,1,2,3,0>", "HIP events around one graph-replayed run of 512 launches", "k_step<1,1,2,3,0>/cooking")}
     env.close()
     return out
 
@@ -513,44 +560,21 @@ def emit(line):
 _REAL_STDOUT = 1
 
 
-_LAST_ENV = None
+WORKLOAD = ("coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"])      # BASELINE configs 2 and 4
+WORKLOAD_KW = dict(action_scheme="scheme3", num_layouts=256, layout_seed=0, auto_reset=True)
 
 
 def worker(args):
-    """Measures with overlapped launches first (unless CZ_CHAIN=0).  If any rank's library ever abandons a hand-off (it then
-    refuses to go on: the env states are void), that rank declares the attempt's rendezvous void, every rank drops its env
-    and communicator, and all of them measure again with launch-boundary ordering - the line then says so."""
-    global _LAST_ENV
     _redirect_stdout()
     from cooking_zoo_amd import distributed as czd
-    base = czd.FileRendezvous.from_env(timeout=600.0)
-    sim = os.environ.get("CZ_BENCH_SIMULATE_HANDOFF_TIMEOUT")            # test hook: "1" = every rank, "10r" = rank r only
-    want = os.environ.get("CZ_CHAIN", "1") != "0" and (not args.dry_run or bool(sim))
-    note, rc = None, 1
-    for attempt, overlap in enumerate([True, False] if want else [False]):
-        rdzv = base.subdir(f"attempt{attempt}")
-        try:
-            rc = worker_body(args, rdzv, overlap, note)
-            break
-        except Exception as exc:                                  # noqa: BLE001
-            abandoned, poisoned = "gave up waiting" in str(exc), isinstance(exc, czd.RendezvousPoisoned)
-            if not overlap or not (abandoned or poisoned):
-                raise
-            if abandoned:
-                rdzv.poison(str(exc))
-            print(f"bench.py rank {rdzv.rank}: {exc}\nbench.py: measuring again with launch-boundary ordering", file=sys.stderr)
-            note = f"overlapped launches were abandoned in the first attempt ({exc}); measured with launch-boundary ordering"
-            if _LAST_ENV is not None:
-                try:
-                    _LAST_ENV.close()
-                except Exception:                                 # noqa: BLE001
-                    pass
-                _LAST_ENV = None
+    rdzv = czd.FileRendezvous.from_env(timeout=600.0)
     try:
-        base.close()
-    except Exception:                                             # noqa: BLE001
-        pass
-    return rc
+        return worker_body(args, rdzv)
+    finally:
+        try:
+            rdzv.close()
+        except Exception:                                         # noqa: BLE001
+            pass
 
 
 def _redirect_stdout():
@@ -563,22 +587,38 @@ def _redirect_stdout():
     os.dup2(2, 1)
 
 
-def worker_body(args, rdzv, overlap, note):
-    global _LAST_ENV
+def timed_regions(senv, K, R, ring, outs, first_slot_of):
+    """R regions of K steps of the whole batch: stream sync + all-rank barrier, K launches per shard (cz_step_device_ring: graph
+    replay), stream sync; -> (elapsed seconds, env-steps executed by this process's shards) per region"""
+    elapsed, steps_done = [], []
+    period = ring.leading[0]
+    for r in range(R):
+        s0 = sum(st["env_steps"] for st in senv._each(lambda i, env: env.stats()))
+        senv.barrier()                                           # stream sync + all-rank barrier
+        t0 = time.perf_counter()
+        senv.step_device_ring(K, ring, period, first_slot_of(r), *outs)
+        senv.sync()
+        elapsed.append(time.perf_counter() - t0)
+        senv.barrier()
+        steps_done.append(sum(st["env_steps"] for st in senv._each(lambda i, env: env.stats())) - s0)   # (auto-reset passes are not counted)
+    return elapsed, steps_done
+
+
+def worker_body(args, rdzv):
     from cooking_zoo_amd import distributed as czd
+    from cooking_zoo_amd.sharded import ShardedVecEnv
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used", file=sys.stderr)
     N, K, Wm, R = args.envs, args.steps, args.warmup, max(1, args.repeats)
-    begin, count = czd.shard_range(N * world, world, rank)
+    sharded = dict(device_ids=[local_rank], world_size=world, rank=rank, rendezvous=rdzv if world > 1 else None)
 
-    sim = os.environ.get("CZ_BENCH_SIMULATE_HANDOFF_TIMEOUT")
     if args.dry_run:
-        if overlap and sim and (sim == "1" or int(sim) == rank + 100):
-            raise RuntimeError("simulated: an overlapped launch gave up waiting for its predecessor")
-        b4, n4 = czd.shard_range(CFG4_ENVS_PER_GPU * world, world, rank)
+        plan = ShardedVecEnv(N * world, *WORKLOAD, dry_run=True, **sharded, **WORKLOAD_KW)
+        plan4 = ShardedVecEnv(CFG4_ENVS_PER_GPU * world, *WORKLOAD, dry_run=True, tables=None, **sharded, **dict(WORKLOAD_KW, num_layouts=4))
+        (begin, count), (b4, n4) = plan.ranges[0], plan4.ranges[0]
         mine = {"elapsed_s": [1e-3 * (rank + 1 + 0.01 * r) for r in range(R)], "env_steps": [K * count] * R,
                 "kernel_us": [1.0] * R, "stats": {"env_steps": K * count * R},
                 "device_id": local_rank, "rank": rank, "env_id_base": begin, "cfg4": {"env_id_base": b4, "envs": n4,
@@ -589,32 +629,22 @@ def worker_body(args, rdzv, overlap, note):
                     "n_gpus": world, "steps": K, "warmup": Wm, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                     "dtype": "u8/u32 state, f64 obs+reward", "data": "DRY RUN: no GPU work, made-up timings (INVALID as a result)",
                     "config": {"workload": f"dry run, {N} envs per rank x {world} rank(s)"},
-                    "shards": [czd.shard_range(N * world, world, r) for r in range(world)],
+                    "shards": [list(x) for x in plan.plan],
                     "stats_total_env_steps": sum(e["stats"]["env_steps"] for e in every),
                     "device_ids": [e["device_id"] for e in every], "env_id_bases": [e["env_id_base"] for e in every]}
             line.update(aggregate(every, K))
             if world > 1 and not args.no_extras:
                 line["config4"] = config4_block(world, [e["cfg4"] for e in every], None)
-            if note:
-                line["overlap_fallback"] = note
             emit(line)
-        rdzv.close()
         return 0
 
     from cooking_zoo_amd import _native
-    from cooking_zoo_amd.vec_env import CookingVecEnv
-    env = CookingVecEnv(count, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"],
-                        action_scheme="scheme3", num_layouts=256, layout_seed=0, auto_reset=True,
-                        device_id=local_rank, env_id_base=begin)
-    _LAST_ENV = env
+    # the batch: N envs per GPU x world GPUs, this process's shard on device LOCAL_RANK; RCCL communicator under a deadline
+    senv = ShardedVecEnv(N * world, *WORKLOAD, comm_deadline=COMM_DEADLINE_S, **sharded, **WORKLOAD_KW)
+    env = senv.shards[0]                                   # (the single-handle legs below talk to this rank's handle)
     L, h = _native.lib(), env._h
-    env.reset(return_obs=False)
-    # this process drives one handle on its GPU: runs of step launches may overlap (cz_set_overlap in include/cookingzoo.h;
-    # CZ_CHAIN=0 keeps the launch-boundary ordering with graph replay)
-    if overlap:
-        env.set_overlap(True)
-        if sim and (sim == "1" or int(sim) == rank + 100):         # test hook for the second attempt
-            raise RuntimeError("simulated: an overlapped launch gave up waiting for its predecessor")
+    comm_ok, comm_msg = senv.comm_kind == "rccl", senv.comm_note
+    senv.reset(return_obs=False)
 
     # inputs resident in HBM: a ring of int32 [N, A] action tensors, one slot per step (uniform over the 5 scheme3
     # actions); outputs: obs f64 [N, A, F], rewards f64, terminations / truncations u8.  The ring holds a whole number of
@@ -622,117 +652,83 @@ def worker_body(args, rdzv, overlap, note):
     runs_in_ring = max(1, 256 // K) if K <= 256 else 1
     period = K * runs_in_ring if K <= 256 else 256
     rng = np.random.default_rng(1234 + rank)
-    d_actions = env.alloc((period, N, 2), np.int32)
-    d_actions.from_host(rng.integers(0, 5, size=(period, N, 2), dtype=np.int32))
-    d_obs = env.alloc((N, 2, env.F), np.float64)
-    d_rew = env.alloc((N, 2), np.float64)
-    d_term = env.alloc((N, 2), np.uint8)
-    d_trunc = env.alloc((N, 2), np.uint8)
-    obs_ptr = None if args.no_obs else d_obs.ptr
-    ring = (d_actions.ptr, N * 2, period)
-    outs = (obs_ptr, d_rew.ptr, d_term.ptr, d_trunc.ptr)
-
-    def run_steps(k, first_slot):
-        # k launches of the step kernel, one per env step, issued from C (cz_step_device_ring: graph replay of the run)
-        _native.check(h, L.cz_step_device_ring(h, k, *ring, first_slot % period, *outs))
+    ring = senv.alloc((2,), np.int32, leading=(period,))
+    ring.from_host(rng.integers(0, 5, size=(period, senv.local_envs, 2), dtype=np.int32))
+    s_obs, s_rew = senv.alloc((2, env.F), np.float64), senv.alloc((2,), np.float64)
+    s_term, s_trunc = senv.alloc((2,), np.uint8), senv.alloc((2,), np.uint8)
+    outs = (None if args.no_obs else s_obs, s_rew, s_term, s_trunc)
+    d_actions, d_obs, d_rew, d_term, d_trunc = ring.parts[0], s_obs.parts[0], s_rew.parts[0], s_term.parts[0], s_trunc.parts[0]
 
     def first_slot_of(r):
         return (r % runs_in_ring) * K if K <= 256 else 0
 
     # one-off graph captures outside the measurement (nothing is stepped)
     if Wm > 0:
-        _native.check(h, L.cz_ring_prepare(h, Wm, *ring, 0, *outs))
+        senv.ring_prepare(Wm, ring, period, 0, *outs)
     for r in range(min(R, runs_in_ring)):
-        _native.check(h, L.cz_ring_prepare(h, K, *ring, first_slot_of(r), *outs))
-
-    # ---- the communicator: RCCL over xGMI through the C-ABI, under a deadline (helper thread; every rank learns the outcome)
-    comm_ok, comm_msg = czd.comm_init_with_deadline(env, world, rank, rdzv, COMM_DEADLINE_S)
-
-    def barrier():
-        env.sync()
-        rdzv.barrier()
-        if comm_ok:
-            _native.check(h, L.cz_comm_barrier(h))         # GPU-side: every rank's stream has drained
-
+        senv.ring_prepare(K, ring, period, first_slot_of(r), *outs)
     if Wm > 0:
-        run_steps(Wm, 0)
+        senv.step_device_ring(Wm, ring, period, 0, *outs)
     L.cz_launch_counts(h, None, None, 1)
-    L.cz_chain_counts(h, None, 1)
-    elapsed, steps_done = [], []
-    for r in range(R):
-        s0 = env.stats()["env_steps"]
-        barrier()                                              # stream sync + all-rank barrier
-        t0 = time.perf_counter()
-        run_steps(K, first_slot_of(r))
-        env.sync()
-        elapsed.append(time.perf_counter() - t0)
-        barrier()
-        steps_done.append(env.stats()["env_steps"] - s0)       # world steps executed (auto-reset passes are not counted)
-    g_k, d_k, c_k = C.c_int64(), C.c_int64(), C.c_int64()
+    elapsed, steps_done = timed_regions(senv, K, R, ring, outs, first_slot_of)
+    g_k, d_k = C.c_int64(), C.c_int64()
     L.cz_launch_counts(h, C.byref(g_k), C.byref(d_k), 0)
-    L.cz_chain_counts(h, C.byref(c_k), 0)
 
-    # dominant-kernel duration: HIP events on the kernels' own stream around max(R*K, 4000) launches issued back to back (the
-    # host <-> GPU round trip of a synchronised region, ~20 us on this platform whatever K is, is not kernel time)
+    # dominant-kernel duration: HIP events on the kernels' own stream around max(R*K, 4000) of the SAME launches issued back to back
+    # (the host <-> GPU round trip of a synchronised region, ~20 us on this platform whatever K is, is not kernel time)
     ev_ms = C.c_float()
     n_ev = max(R * K, 4000)
-    _native.check(h, L.cz_ring_prepare(h, n_ev, *ring, 0, *outs))
-    barrier()
+    senv.ring_prepare(n_ev, ring, period, 0, *outs)
+    senv.barrier()
     _native.check(h, L.cz_timer_start(h))
-    run_steps(n_ev, 0)                                         # the ring end to end, as few replays as possible
-    _native.check(h, L.cz_timer_stop(h, C.byref(ev_ms)))       # event after the last launch, synchronised (fails if a hand-off was abandoned)
-    kernel_us = [ev_ms.value * 1e3 / n_ev]
-    # the same launches ordered by launch boundaries only (overlap switched off for this pass): the duration of one kernel
-    # when nothing runs beside it, which is what a per-kernel trace of such a run shows
-    was = max(L.cz_set_overlap(h, 0), 0)
-    _native.check(h, L.cz_ring_prepare(h, n_ev, *ring, 0, *outs))
-    barrier()
-    _native.check(h, L.cz_timer_start(h))
-    run_steps(n_ev, 0)
-    _native.check(h, L.cz_timer_stop(h, C.byref(ev_ms)))
-    kernel_us.append(ev_ms.value * 1e3 / n_ev)
-    L.cz_set_overlap(h, was)
-    overlapped = bool(c_k.value)
-    mine = {"elapsed_s": elapsed, "env_steps": steps_done, "kernel_us": kernel_us, "stats": env.stats()}
+    env.step_device_ring(n_ev, d_actions, env.num_envs * 2, period, 0, None if args.no_obs else d_obs, d_rew, d_term, d_trunc)
+    _native.check(h, L.cz_timer_stop(h, C.byref(ev_ms)))       # event after the last launch, synchronised
+    kernel_us = ev_ms.value * 1e3 / n_ev
+    mine = {"elapsed_s": elapsed, "env_steps": steps_done, "kernel_us": [kernel_us], "stats": env.stats()}
     every = [json.loads(b) for b in rdzv.all_gather(json.dumps(mine).encode())]
+
+    # ---- a sustained stretch of the headline's launches (a sampler of GPU activity sees the device busy)
+    sustained = None
+    if not args.no_extras:
+        n_s = max(2000, K)
+        senv.barrier()
+        t0 = time.perf_counter()
+        reps_s = 0
+        while time.perf_counter() - t0 < 2.0:
+            senv.step_device_ring(n_s, ring, period, 0, *outs)
+            reps_s += 1
+            if reps_s % 8 == 0:
+                senv.sync()
+        senv.sync()
+        dt_s = time.perf_counter() - t0
+        sustained = {"seconds": dt_s, "launches": reps_s * n_s, "us_per_step": dt_s * 1e6 / (reps_s * n_s),
+                     "env_steps_per_s_per_gpu": 400.0 / 401.0 * senv.local_envs * reps_s * n_s / dt_s,
+                     "what": f"runs of {n_s} graph-replayed launches of the same kernel, back to back for two seconds, synchronised every 8 runs"}
 
     # ---- BASELINE config 4 when there are several ranks: 262144 envs over 8 GPUs = 32768 envs per rank, global env ids (the
     # statistics exchange below is that config's only collective); every rank times the same K-step regions between barriers
     cfg4_every = None
     if world > 1 and not args.no_extras:
         K4, R4 = CFG4_K, 5
-        base4, n4 = czd.shard_range(CFG4_ENVS_PER_GPU * world, world, rank)
-        env4 = CookingVecEnv(n4, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3",
-                             num_layouts=256, layout_seed=0, auto_reset=True, device_id=local_rank, env_id_base=base4)
-        env4.reset(return_obs=False)
-        d_ring4 = env4.alloc((16, n4, 2), np.int32)
-        d_ring4.from_host(np.random.default_rng(99 + rank).integers(0, 5, size=(16, n4, 2), dtype=np.int32))
-        o4 = (env4.alloc((n4, 2, env4.F), np.float64).ptr, env4.alloc((n4, 2), np.float64).ptr, env4.alloc((n4, 2), np.uint8).ptr,
-              env4.alloc((n4, 2), np.uint8).ptr)
-        h4 = env4._h
-        _native.check(h4, L.cz_ring_prepare(h4, K4, d_ring4.ptr, n4 * 2, 16, 0, *o4))
-        _native.check(h4, L.cz_step_device_ring(h4, 16, d_ring4.ptr, n4 * 2, 16, 0, *o4))
-        el4, st4 = [], []
-        for r in range(R4):
-            s0 = env4.stats()["env_steps"]
-            env4.sync(); barrier()
-            t0 = time.perf_counter()
-            _native.check(h4, L.cz_step_device_ring(h4, K4, d_ring4.ptr, n4 * 2, 16, 0, *o4))
-            env4.sync()
-            el4.append(time.perf_counter() - t0)
-            barrier()
-            st4.append(env4.stats()["env_steps"] - s0)
+        senv4 = ShardedVecEnv(CFG4_ENVS_PER_GPU * world, *WORKLOAD, comm="host", **sharded, **WORKLOAD_KW)
+        senv4.reset(return_obs=False)
+        ring4 = senv4.alloc((2,), np.int32, leading=(16,))
+        ring4.from_host(np.random.default_rng(99 + rank).integers(0, 5, size=(16, senv4.local_envs, 2), dtype=np.int32))
+        o4 = (senv4.alloc((2, senv4.F), np.float64), senv4.alloc((2,), np.float64), senv4.alloc((2,), np.uint8), senv4.alloc((2,), np.uint8))
+        senv4.ring_prepare(K4, ring4, 16, 0, *o4)
+        senv4.step_device_ring(16, ring4, 16, 0, *o4)
+        el4, st4 = timed_regions(senv4, K4, R4, ring4, o4, lambda r: 0)
         cfg4_every = [json.loads(b) for b in rdzv.all_gather(json.dumps({"elapsed_s": el4, "env_steps": st4, "kernel_us": [0.0] * R4,
-                                                                         "env_id_base": base4, "envs": n4}).encode())]
-        b_alg4 = algorithmic_bytes_per_env_step(env4)
-        env4.close()
+                                                                         "env_id_base": senv4.local_begin, "envs": senv4.local_envs}).encode())]
+        b_alg4 = algorithmic_bytes_per_env_step(senv4.shards[0])
+        senv4.close()
 
-    # ---- episode statistics: RCCL all-gather over xGMI of one cz_stats per rank (the path's only collective), checked
+    # ---- episode statistics: RCCL all-gather over xGMI of one cz_stats per shard (the path's only collective), checked
     # against the same structs exchanged over the control plane
     stats_all = {}
     rc = 0
     if comm_ok:
-        done, res = with_deadline(lambda: czd.allgather_stats_rccl(env, world), COMM_DEADLINE_S)
+        done, res = with_deadline(senv.stats_per_shard, COMM_DEADLINE_S)
         if not done:
             stats_all["cz_stats_allgather"] = f"timed out after {COMM_DEADLINE_S:.0f} s"
             rc = EXIT_COMM_FAILED
@@ -754,29 +750,29 @@ def worker_body(args, rdzv, overlap, note):
 
     if rank == 0:
         agg = aggregate(every, K)
-        kernel_med = kernel_us[0]
         # the floor of a launch that has to emit this much output: same grid shape, nothing but the stores
         out_only_us = None
         if not args.no_obs:
             us = C.c_float()
             if L.cz_probe_output_only(h, d_obs.ptr, N * 2 * env.F * 8, 500, C.byref(us)) == 0:
                 out_only_us = float(us.value)
-        # secondary figure: the same work fused, T steps per launch with the on-device action stream and a trajectory buffer
-        fused = None if args.no_obs else guarded(leg_fused, env, K)
-        if fused is not None and "error" in fused:
-            line_fused_error, fused = fused, None
-        else:
-            line_fused_error = None
         rccl_path, hip_path = C.create_string_buffer(512), C.create_string_buffer(512)
         L.cz_runtime_paths(rccl_path, hip_path, 512)
         b_alg = algorithmic_bytes_per_env_step(env)
-        achieved = b_alg * N / (kernel_med * 1e-6) / 1e9
-        total_k = g_k.value + d_k.value + c_k.value
-        api = (f"cz_step_device_ring: one kernel launch per env step; of the {total_k} timed launches {c_k.value} went out as "
-               f"overlapped launches (two streams alternately, each env's step ordered after that env's previous step by a "
-               f"sequence word instead of a launch boundary), {g_k.value} were replayed from HIP graphs of "
-               f"{K if K <= 256 else 'up to 256'} launches and {d_k.value} launched directly; "
-               f"actions/obs/rewards/flags resident in HBM")
+        api = (f"cooking_zoo_amd.ShardedVecEnv.step_device_ring -> cz_step_device_ring: one launch of cz::k_step<1,1,2,3,0> per env step, ordered "
+               f"by launch boundaries; of the {g_k.value + d_k.value} timed launches 0 went out as overlapped launches (that mode was removed in "
+               f"round 5), {g_k.value} were replayed from HIP graphs of {K if K <= 256 else 'up to 256'} launches and {d_k.value} launched "
+               f"directly; actions/obs/rewards/flags resident in HBM")
+        roof = roofline_block(b_alg, N, kernel_us, "cz::k_step<1,1,2,3,0> (one wavefront per env, 8 envs per workgroup)",
+                              f"HIP events on the kernels' stream around {n_ev} launches issued back to back (graph replay, ordered by launch "
+                              f"boundaries) - the launches `value` times -, divided by the number of launches; rocprofv3 --kernel-trace of the same "
+                              f"command: profiles/r05/kernel_stats.csv", "k_step<1,1,2,3,0>")
+        roof["traffic"] = pmc_traffic(f"k_step_{N}")
+        roof["traffic_from"] = "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately) of the same kernel: profiles/r05/traffic.json (r04's until collected)"
+        # measured on this box, same run: a kernel of the same grid shape that ONLY writes the observation bytes (write-through
+        # 16-byte stores); write-only traffic does not reach the 8 TB/s read+write peak
+        roof["output_only_launch_us"] = out_only_us
+        roof["frac_of_output_only_launch"] = (out_only_us / kernel_us) if out_only_us else None
         line = {
             "metric": "env-steps/sec at N parallel envs (1/2/4/8 GPU) + achieved HBM GB/s",
             "value": agg["value"], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -789,47 +785,26 @@ def worker_body(args, rdzv, overlap, note):
                                    f"max_steps=400, f64 obs F={env.F}",
                        "details": "256-layout pool, on-device next-step auto-reset, feature_vector observation encoded every step, uniform random "
                                   "actions resident in HBM, device-resident outputs",
-                       "envs_per_gpu": N, "parallelism": f"env-sharded x{world}, one wavefront per env, one process per GPU, no torch",
+                       "envs_per_gpu": N, "parallelism": f"env-sharded x{world} (ShardedVecEnv: {senv.comm_note}), one wavefront per env, one process per GPU, no torch",
                        "api": api},
-            # The dominant kernel's roofline is quoted from the launch-boundary-ordered kernel, cz::k_step<1,1,2,3,0>: its HIP-event
-            # launch duration agrees with rocprofv3's per-kernel average for that kernel (profiles/r04/kernel_stats_ordered.csv).  When
-            # the timed regions ran as overlapped launches, the launch-to-launch interval of those is given next to it, with
-            # the device-clock timeline that shows it (a per-kernel trace cannot: two of those kernels are resident at a time).
-            "roofline": {"bound": "hbm", "achieved": b_alg * N / (kernel_us[1] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": b_alg * N / (kernel_us[1] * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(f"k_step_{N}"),
-                         "kernel": "cz::k_step<1,1,2,3,0> (one wavefront per env, 8 envs per workgroup)",
-                         "kernel_us": kernel_us[1],
-                         "kernel_us_from": (f"HIP events on the kernels' stream around {max(R * K, 4000)} launches issued back to back (graph replay, "
-                                            f"ordered by launch boundaries), divided by the number of launches; rocprofv3 --kernel-trace of the same "
-                                            f"launches: profiles/r04/kernel_stats_ordered.csv"),
-                         "traffic_from": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately) of the same kernel: profiles/r04/traffic.json",
-                         "alg_bytes_per_env_step": b_alg, "units_per_launch": N,
-                         "overlapped_launch_interval_us": kernel_med if overlapped else None,
-                         "overlapped_frac": (achieved / HBM_PEAK_GBS) if overlapped else None,
-                         "overlapped_from": ("HIP events around the same number of OVERLAPPED launches (two streams alternately, per-env sequence words: "
-                                             "cz::k_step_chain<1,1,2,3>); the device-clock timeline of such a run - start-to-start interval of "
-                                             "consecutive launches - is profiles/r04/timeline_overlapped.json") if overlapped else None,
-                         # measured on this box, same run: a kernel of the same grid shape that ONLY writes the observation
-                         # bytes (write-through 16-byte stores); write-only traffic does not reach the 8 TB/s read+write peak
-                         "output_only_launch_us": out_only_us,
-                         "frac_of_output_only_launch": (out_only_us / kernel_us[1]) if out_only_us else None},
+            "roofline": roof,
             "achieved_hbm_gbs_end_to_end": b_alg * agg["value"] / 1e9 / world,
             "runtime": {"hip": hip_path.value.decode(), "rccl": rccl_path.value.decode(), "torch_imported": "torch" in sys.modules},
             "episode_stats_allgather": stats_all,
         }
-        if note:
-            line["overlap_fallback"] = note
-        if line_fused_error is not None:
-            line["fused_rollout"] = line_fused_error
-        if fused is not None:
+        if sustained is not None:
+            line["sustained"] = sustained
+        if not args.no_obs:
+            fused = guarded(leg_fused, env, K)
+            if "error" not in fused:
+                fused["roofline"] = roofline_block(b_alg, N, fused["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,1> (32 steps per launch)",
+                                                   "wall clock around the cz_rollout launches", "k_step<1,1,2,3,1>")
             line["fused_rollout"] = fused
-            fused["roofline"] = roofline_block(b_alg, N, fused["ms_per_step"] * 1e3, "cz::k_step<1,1,2,3,1> (32 steps per launch)",
-                                               "wall clock around the cz_rollout launches")
         if cfg4_every is not None:
             line["config4"] = config4_block(world, cfg4_every, b_alg4)
         if world == 1 and not args.no_extras and not args.no_obs:
-            # what users get beside the open-loop headline; each leg a fraction of a second of GPU time.
-            # An extra leg must never be able to lose the headline measured above: whatever it raises is recorded under its key.
+            # what users get beside the open-loop headline; each leg a fraction of a second of GPU time.  An extra leg must never be
+            # able to lose the headline measured above: whatever it raises is recorded under its key.
             line["fused_actions"] = guarded(leg_fused_actions, env, K)
             line["fused_compact"] = guarded(leg_fused_compact, env, K)
             line["ring_fused"] = guarded(leg_ring_fused, env, K, d_obs, d_rew, d_term, d_trunc)
@@ -840,16 +815,10 @@ def worker_body(args, rdzv, overlap, note):
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = guarded(cpu_baseline, env)
         emit(line)
-    try:
-        rdzv.close()
-    except Exception:
-        pass
     sys.stdout.flush()
     if rc != 0:
-        sys.stdout.flush()
         os._exit(rc)                             # a communicator stuck in bring-up cannot be torn down: leave, visibly failed
-    env.close()
-    _LAST_ENV = None
+    senv.close()
     return 0
 
 
