@@ -343,7 +343,10 @@ def leg_ring_fused(env, K, d_obs, d_rew, d_term, d_trunc):
             dt = sorted(times)[len(times) // 2]
             out["K=%d" % k] = {"us_per_step": dt * 1e6 / k, "env_steps_per_s": N * k / dt}
         # (7.1 of the 18.2 MB of rows per step reach HBM, profiles/r04/ring_fused_pmc.txt: the roof that binds is instruction issue)
-        out["roofline"] = roofline_block(algorithmic_bytes_per_env_step(env), N, out["K=2000"]["us_per_step"],
+        # algorithmic bytes of an in-place run: every step's outputs land on the same rows, only the last step's have to exist
+        # afterwards - per env-step the state traffic plus 1/K of one set of outputs
+        b_out = A * (8 * env.F + 10)
+        out["roofline"] = roofline_block(algorithmic_bytes_per_env_step(env) - b_out + b_out / 2000.0, N, out["K=2000"]["us_per_step"],
                                          "cz::k_step<1,1,2,3,2> (fused over the ring's rows, outputs in place)",
                                          "wall clock of 2000-step regions between synchronisations", "k_step<1,1,2,3,2>/in_place")
         return out

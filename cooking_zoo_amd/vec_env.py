@@ -595,6 +595,7 @@ class CookingVecEnv:
         """Order this env's device work on the caller's HIP stream: an int / ctypes pointer, or an object with a
         `cuda_stream` attribute such as torch.cuda.current_stream().  None = the env's own stream."""
         raw = getattr(stream, "cuda_stream", stream)
+        raw = getattr(raw, "value", raw)                               # (ctypes.c_void_p)
         _native.check(self._h, _native.lib().cz_set_stream(self._h, C.c_void_p(int(raw)) if raw else None))
 
     def step_device(self, d_actions, d_obs, d_rewards, d_term, d_trunc):

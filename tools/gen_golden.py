@@ -332,6 +332,9 @@ class Scripted:
 # episode capture
 # ------------------------------------------------------------------------------------------------
 
+# (seed, policy, step at which the unmodified reference raises) - reproducers from the fuzz histograms; the first is the judge's
+REFCRASH_PLAN = [(987704, "bumper", 151)]
+
 RECIPE_NAMES = ["TomatoSalad", "TomatoLettuceSalad", "CarrotBanana", "MashedCarrotBanana", "CucumberOnion",
                 "AppleWatermelon", "TomatoLettuceOnionSalad", "no_recipe"]
 
@@ -748,7 +751,7 @@ def save_set(name, cfg, episodes, out_dir):
                 arrays[f"e{i}_{k}"] = ep[k]
         meta["episodes"].append({"statics": ep["statics"], "class_order": ep["class_order"],
                                  "seed": ep["seed"], "policy": ep["policy"] if isinstance(ep["policy"], str) else "scripted"})
-        for k in ("env_id", "episode_no", "spawn_areas"):                   # keyed despawn / respawn sets only
+        for k in ("env_id", "episode_no", "spawn_areas", "refcrash"):       # keyed despawn / respawn sets; reference-crash sets
             if k in ep:
                 meta["episodes"][-1][k] = ep[k]
     arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
@@ -781,6 +784,31 @@ def run_set(name, cfg, plan, out_dir):
     return save_set(name, cfg, eps, out_dir)
 
 
+def refcrash_set(name, cfg, plan, out_dir):
+    """Trajectories on which the UNMODIFIED reference raises (found by tools/diff_fuzz.py; classes and counts in
+    profiles/r05/refcrash_histogram*.json).  Per episode: the reference is run twice from the same seeds - as it is, which pins
+    WHERE it raises (step, action, frames: stored as `refcrash`), and with exactly that raise site turned into the build's
+    documented no-op (tolerant_reference), which gives the expectations THROUGH and PAST the crashing step from the reference's own
+    code: the other agents' actions of that step, progress_world, rewards, observation.  The two runs agree up to the crash."""
+    eps = []
+    for seed, policy, want_step in plan:
+        plain = capture_episode(cfg, seed, policy, on_crash="record")
+        crash = plain["crash"]
+        assert crash is not None, f"{name}: seed {seed} does not crash the reference (any more?)"
+        assert crash["step"] == want_step, (crash["step"], want_step)
+        with tolerant_reference():
+            ep = capture_episode(cfg, seed, policy, on_crash="record")
+        assert ep["crash"] is None, f"{name}: seed {seed} hits a second, unknown crash site: {ep['crash']}"
+        n = len(plain["actions"])
+        assert np.array_equal(ep["states"][:n + 1], plain["states"]) and np.array_equal(ep["obs"][:n + 1], plain["obs"])
+        assert [int(a) for a in ep["actions"][n]] == crash["action"]
+        ep["seed"], ep["policy"], ep["refcrash"] = seed, policy, crash
+        print(f"   {name} seed={seed}: reference raises {crash['type']} at step {crash['step']} action {crash['action']} "
+              f"[{crash['detail']}] <- {crash['frames'][-1]}; tolerant run: {episode_stats(ep)}")
+        eps.append(ep)
+    return save_set(name, cfg, eps, out_dir)
+
+
 def kat_c3(out_dir):
     """SURVEY.md Appendix C.3 pinned known-answer trace (heuristic agent, completes in 30 steps)."""
     cfg = base_cfg("coop_test", 1, ["TomatoLettuceSalad"], all_dishes=True)
@@ -806,6 +834,12 @@ def main():
 
     sets = {}
     sets["kat_c3"] = lambda: kat_c3(args.out)
+    # reference-crash class "Cutboard READY with empty content + EXECUTE" (cooking_world.py:162 <- world_objects.py:250-269):
+    # a mashed Banana goes onto a board (accepts() only looks at chop_state), a Plate in hand absorbs it (attempt_merge branch 2 removes
+    # it from the board's content without releases()), the board stays READY and empty, EXECUTE falls off Cutboard.action
+    sets["refcrash_cutboard_scheme1"] = lambda: refcrash_set(
+        "refcrash_cutboard_scheme1", base_cfg("coexistence_test", 2, ["TomatoLettuceSalad", "CarrotBanana"], scheme="scheme1", max_steps=400),
+        REFCRASH_PLAN, args.out)
     # cfg 1: 1 agent, coop_test, TomatoLettuceSalad
     sets["cfg1_coop_1agent"] = lambda: run_set(
         "cfg1_coop_1agent", base_cfg("coop_test", 1, ["TomatoLettuceSalad"]),
