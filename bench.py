@@ -599,8 +599,7 @@ def timed_regions(senv, K, R, ring, outs, first_slot_of):
         s0 = sum(st["env_steps"] for st in senv._each(lambda i, env: env.stats()))
         senv.barrier()                                           # stream sync + all-rank barrier
         t0 = time.perf_counter()
-        senv.step_device_ring(K, ring, period, first_slot_of(r), *outs)
-        senv.sync()
+        senv.step_device_ring_sync(K, ring, period, first_slot_of(r), *outs)
         elapsed.append(time.perf_counter() - t0)
         senv.barrier()
         steps_done.append(sum(st["env_steps"] for st in senv._each(lambda i, env: env.stats())) - s0)   # (auto-reset passes are not counted)

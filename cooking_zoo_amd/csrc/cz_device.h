@@ -518,7 +518,10 @@ struct Ops {
             if (!(sv & CELL_READY)) return;
             const OM fresh = dyn & outside_plates(e) & m_d0(e, D_CHOPPED, 0u);
             const int f = fresh.first();                    // first content item whose chop() executes
-            if (f < 0) return;                              // reference falls off Cutboard.action (TypeError); unreachable
+            // No such item on a READY board: the reference falls off Cutboard.action -> None -> TypeError at cooking_world.py:162.
+            // REACHABLE (a mashed Banana on the board, absorbed by a Plate in hand through attempt_merge branch 2, leaves it READY and
+            // empty); the build's answer is a no-op, pinned by tests/golden/refcrash_cutboard_scheme1.npz.
+            if (f < 0) return;
             const uint32_t fw = slot_d0(e, f);
             slot_or(e, cx, f, D_CHOPPED);
             if ((fw & 0xFF0000u) == (BREAD << 16)) {

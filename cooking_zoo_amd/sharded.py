@@ -109,7 +109,9 @@ class ShardedVecEnv:
             setattr(self, name, getattr(tables, name))
         if self.dry_run:
             return
-        self._pools = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"cz-shard{g}") for g in self.shard_ids]
+        # one host thread per handle; a single local shard is driven by the calling thread itself (a thread hop costs tens of
+        # microseconds per call - more than a 20-step region's synchronisation)
+        self._pools = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"cz-shard{g}") for g in self.shard_ids] if k > 1 else [None]
         try:
             self.shards = [None] * k
             made = self._each(lambda i, _: CookingVecEnv(self.ranges[i][1], tables=tables.shard(*self.ranges[i]), auto_reset=auto_reset,
@@ -126,6 +128,8 @@ class ShardedVecEnv:
         (in shard order) is re-raised after all of them have finished."""
         if self.dry_run:
             raise RuntimeError("ShardedVecEnv(dry_run=True) holds a plan only: no device work")
+        if len(self._pools) == 1 and self._pools[0] is None:
+            return [fn(0, self.shards[0] if need_env else None)]
         futs = [pool.submit(fn, i, self.shards[i] if need_env else None) for i, pool in enumerate(self._pools)]
         out, err = [], None
         for f in futs:
@@ -181,7 +185,8 @@ class ShardedVecEnv:
                 box[i] = "" if rc == 0 else (L.cz_last_error(env._h) or b"cz_comm_init failed").decode()
 
             # ncclCommInitRank blocks until every rank has joined: all shards at once, each on its own thread, under a deadline
-            futs = [pool.submit(bring_up, i, self.shards[i]) for i, pool in enumerate(self._pools)]
+            pools = self._pools if self._pools[0] is not None else [ThreadPoolExecutor(max_workers=1, thread_name_prefix="cz-comm")]
+            futs = [pool.submit(bring_up, i, self.shards[i]) for i, pool in enumerate(pools)]
             done = threading.Event()
 
             def wait_all():
@@ -290,6 +295,16 @@ class ShardedVecEnv:
         self._each(lambda i, env: env.step_device_ring(K, P(d_ring, i), env.num_envs * env.num_agents, action_period, first_slot,
                                                         P(d_obs, i), P(d_rewards, i), P(d_term, i), P(d_trunc, i)))
 
+    def step_device_ring_sync(self, K, d_ring, action_period, first_slot, d_obs, d_rewards, d_term, d_trunc):
+        """`step_device_ring` + `sync` in one fan-out (one thread hop per shard instead of two)"""
+        P = self._part
+
+        def run(i, env):
+            env.step_device_ring(K, P(d_ring, i), env.num_envs * env.num_agents, action_period, first_slot, P(d_obs, i), P(d_rewards, i),
+                                 P(d_term, i), P(d_trunc, i))
+            env.sync()
+        self._each(run)
+
     def ring_prepare(self, K, d_ring, action_period, first_slot, d_obs, d_rewards, d_term, d_trunc):
         """build the HIP graphs of such a run up front (nothing is stepped)"""
         P = self._part
@@ -347,10 +362,11 @@ class ShardedVecEnv:
             env = self.shards[i] if i < len(self.shards) else None
             if env is not None and not stuck:
                 try:
-                    pool.submit(env.close).result(timeout=60)
+                    env.close() if pool is None else pool.submit(env.close).result(timeout=60)
                 except BaseException:                                 # noqa: BLE001
                     pass
-            pool.shutdown(wait=not stuck)
+            if pool is not None:
+                pool.shutdown(wait=not stuck)
         self._pools, self.shards = [], []
 
     def __enter__(self):

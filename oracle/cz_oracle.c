@@ -404,11 +404,15 @@ static void resolve_execute_action(World *w, Agent *ag)
     Stat *st = &w->cell[ly * w->W + lx];
     if (st->type == CUTBOARD) {
         if (!st->ready) return;
+        /* REFERENCE CRASH, reachable: a READY board whose loop executes nothing - empty content (a mashed Banana was put on it,
+           accepts() :270-272 only looks at chop_state, and a Plate in hand absorbed it through attempt_merge branch 2,
+           cooking_world.py:250-256, which removes it from `content` without releases()) - falls off Cutboard.action, returns None,
+           and cooking_world.py:162 raises TypeError.  Build: nothing created, deleted or executed; the board stays READY.
+           Pinned by tests/golden/refcrash_cutboard_scheme1.npz (reference with that raise site as this no-op). */
         for (int i = 0; i < st->ncontent; ++i) {
             Dyn *o = &w->obj[st->content[i]];
             /* ChopFood.chop abstract_classes.py:250-254 */
-            if (o->chopped) continue;            /* action_executed False -> loop continues (then falls off: TypeError
-                                                    in the reference; unreachable, READY => exactly one FRESH item) */
+            if (o->chopped) continue;            /* action_executed False -> the loop goes on and falls off its end */
             o->chopped = 1;
             if (o->cls == BREAD) {
                 /* new chopped Bread at the same cell, appended to the board content and to world_objects["Bread"]:

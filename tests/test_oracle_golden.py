@@ -107,3 +107,38 @@ def test_oracle_replays_despawn_respawn_steps(name):
             assert np.array_equal(bits(orc.observe(ep.states[t + 1].copy())), bits(ep.obs[t + 1])), ctx
             n_inactive += int((ep.actions[t] < 0).sum())
     assert n_inactive > 20 and n_moved > 3, (n_inactive, n_moved)      # the sets really exercise both directions
+
+
+def refcrash_sets():
+    return [n for n in golden_sets() if n.startswith("refcrash_")]
+
+
+@pytest.mark.parametrize("name", refcrash_sets())
+def test_refcrash_sets_pin_the_no_op_at_the_reference_crash(name):
+    """`refcrash_*`: trajectories on which the unmodified reference RAISES (tools/diff_fuzz.py finds them; the generator stores
+    where: step, action, frames).  The expectations through and past the crashing step come from the reference with exactly that
+    raise site as the build's documented no-op; here: the oracle does at that step what the fixture says, and what it says IS a
+    no-op for the crashing agent (same hands, same cell in front of it) while everything else of the step still happens."""
+    gs = GoldenSet(name)
+    assert name in golden_sets() and gs.episodes
+    for ep, meta_ep in zip(gs.episodes, gs.cfg["episodes"]):
+        crash = meta_ep["refcrash"]
+        assert crash["type"] in ("TypeError", "IndexError", "AttributeError", "ValueError") and crash["frames"], crash
+        t = crash["step"]
+        assert [int(a) for a in ep.actions[t]] == crash["action"] and t < len(ep.actions) - 1
+        orc = make_oracle(gs, ep)
+        rec = ep.states[t].copy()
+        err, obs, rew, term, trunc = orc.step_env(rec, ep.actions[t])
+        assert err == 0 and same_state(ep.dims, rec, ep.states[t + 1])
+        assert np.array_equal(bits(obs), bits(ep.obs[t + 1])) and np.array_equal(bits(rew), bits(ep.rewards[t]))
+        before, after = ep.states[t], ep.states[t + 1]
+        assert int(after[soa.W_T]) == int(before[soa.W_T]) + 1                    # the step itself happened
+        if "Cutboard status=READY content=[]" in crash["detail"]:
+            who = [a for a, act in enumerate(crash["action"]) if act == 7]        # EXECUTE (scheme1)
+            assert who
+            d = ep.dims
+            for a in who:
+                assert before[soa.AGENT_WORD0 + a] == after[soa.AGENT_WORD0 + a]  # position, orientation, hands: unchanged
+            cells_b, cells_a = soa.record_cells(d, before), soa.record_cells(d, after)
+            boards = [c for c in range(d.C) if (cells_b[c] & soa.CELL_TYPE_MASK) == soa.CUTBOARD and (cells_b[c] & soa.CELL_READY)]
+            assert boards and all(cells_a[c] == cells_b[c] for c in boards)       # the board stays READY (and empty)

@@ -5,7 +5,7 @@ O=gpurun_out/r04; mkdir -p $O
 for rep in 1 2; do
   for c in ${CASES:-cfg5 cfg3 cfg4_shard}; do
     for t in . .ab/prev; do
-      (cd $t && CZ_CHAIN=0 timeout 300 python3 tools/bench_configs.py $c 2>/dev/null | python3 -c "
+      (cd $t && timeout 300 python3 tools/bench_configs.py $c 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

@@ -6,6 +6,6 @@ export CZ_LIB=$GRAFT_REPO_ROOT/cooking_zoo_amd/csrc/libcookingzoo_hip_ablate.so
 STEPS=${1:-400}; MODE=${2:-random}
 for m in 1 2 3 4 5 6 7; do
   mkdir -p gpurun_out/stop$m; rm -rf gpurun_out/stop$m/*
-  CZ_CHAIN=0 CZ_STOP=$m timeout 240 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d gpurun_out/stop$m -- python3 tools/step_loop.py $STEPS 4096 $MODE > /dev/null 2>&1
+  CZ_STOP=$m timeout 240 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d gpurun_out/stop$m -- python3 tools/step_loop.py $STEPS 4096 $MODE > /dev/null 2>&1
   echo "$MODE stop=$m $(python3 tools/pmc_summary.py gpurun_out/stop$m '3, 0>' brief)"
 done

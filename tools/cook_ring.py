@@ -6,7 +6,6 @@ import os, sys
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-os.environ["CZ_CHAIN"] = "0"
 os.environ["CZ_GRAPHS"] = "0"
 import bench  # noqa: E402
 from cooking_zoo_amd import _native  # noqa: E402

@@ -16,13 +16,11 @@ from cooking_zoo_amd.vec_env import CookingVecEnv  # noqa: E402
 def main():
     K, N = 2000, 4096
     L = _native.lib()
-    for mode in ("graphs", "direct", "overlapped"):
+    for mode in ("graphs", "direct"):
         if mode == "direct":
             os.environ["CZ_GRAPHS"] = "0"
         env = CookingVecEnv(N, "coop_test", "example", 2, 400, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3", num_layouts=256)
         os.environ.pop("CZ_GRAPHS", None)
-        if mode == "overlapped":
-            env.set_overlap(True)
         env.reset(return_obs=False)
         rng = np.random.default_rng(0)
         d_act = env.alloc((256, N, 2), np.int32)

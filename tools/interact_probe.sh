@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 mkdir -p gpurun_out/ip
-CZ_CHAIN=0 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_SMEM SQ_INSTS_BRANCH --output-format csv -d gpurun_out/ip -- python3 tools/interact_probe.py 2>/dev/null | grep -v "RCCL\|version\|Hostname\|Librccl"
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_SMEM SQ_INSTS_BRANCH --output-format csv -d gpurun_out/ip -- python3 tools/interact_probe.py 2>/dev/null | grep -v "RCCL\|version\|Hostname\|Librccl"
 python3 - <<'PY'
 import csv, glob, collections
 rows = collections.defaultdict(dict)

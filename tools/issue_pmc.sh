@@ -11,6 +11,6 @@ for set in "SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR" \
            "SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_WAVES SQ_IFETCH"; do
   i=$((i + 1)); mkdir -p $O/p$i
-  CZ_CHAIN=0 timeout 300 rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 tools/step_loop.py 400 > $O/p$i.out 2>&1
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 tools/step_loop.py 400 > $O/p$i.out 2>&1
 done
 python3 tools/pmc_summary.py $O '3, 0>' | tee gpurun_out/r04/issue_pmc.txt

@@ -23,10 +23,11 @@ def main():
             continue
         inst, steps = m.group(1), int(m.group(2))
         d = line_file[:-4]
+        want = inst.split("/")[0].replace(",", ", ")                 # "k_step<1,1,2,3,0>/cooking" -> the kernel name's "k_step<1, 1, 2, 3, 0>"
         agg = collections.defaultdict(list)
         for f in glob.glob(d + "*/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                if "k_step<" in r["Kernel_Name"]:
+                if want in r["Kernel_Name"]:
                     agg[r["Counter_Name"]].append(float(r["Counter_Value"]) / (int(r["Grid_Size"]) // 64))
         if "SQ_INSTS_SALU" not in agg:
             continue

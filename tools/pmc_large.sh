@@ -10,11 +10,11 @@ for c in $CASES; do
   for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
     d=$O/${c}_$(echo $pass | cut -d' ' -f1)
     mkdir -p $d
-    CZ_CHAIN=0 timeout 300 rocprofv3 --pmc $pass --output-format csv -d $d -- python3 tools/bench_configs.py $c > $d/out.txt 2>&1
+    timeout 300 rocprofv3 --pmc $pass --output-format csv -d $d -- python3 tools/bench_configs.py $c > $d/out.txt 2>&1
     echo "$c [$pass] rc=$?"
   done
   d=$O/${c}_trace; mkdir -p $d
-  CZ_CHAIN=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 tools/bench_configs.py $c > $d/out.txt 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 tools/bench_configs.py $c > $d/out.txt 2>&1
   echo "$c [trace] rc=$?"
 done
 python3 - <<PY

@@ -6,7 +6,6 @@ import os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-os.environ["CZ_CHAIN"] = "0"
 from cooking_zoo_amd import _native  # noqa: E402
 from cooking_zoo_amd.vec_env import CookingVecEnv  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -3,7 +3,7 @@
 start-to-start interval of consecutive launches, and how many launches were in flight at once.
 
 Ordinary launches (and graph replays) are ordered by launch boundaries: gaps >= 0, interval = duration + gap.  Overlapped
-launches (cz_set_overlap) are resident two at a time: a kernel starts while its predecessor still runs and its waves wait,
+launches (removed in round 5) were resident two at a time: a kernel starts while its predecessor still runs and its waves wait,
 env by env, for the predecessor's - so its duration is about twice the interval and says nothing about the rate; the
 interval (= region time / launches, what bench.py measures with HIP events) does."""
 import csv
