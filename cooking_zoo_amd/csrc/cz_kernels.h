@@ -20,6 +20,10 @@ namespace cz {
 #elif defined(CZ_ABLATE)
 // instruction-count ablation build (make ablate): CZ_STOP=i truncates the step after phase i; no stamps, no asm
 #define CZ_STAMP(i) do { if (P.stop == (i)) return; } while (0)
+#elif defined(CZ_MARKERS)
+// marker build (tools/phase_cut.py, never loaded): an assembler comment at every phase boundary and no instruction - if the
+// instruction stream equals the shipped one (tools/isa_diff.py), the comments are positions in the shipped code
+#define CZ_STAMP(i) asm volatile("; CZ_MARK " #i)
 #else
 #define CZ_STAMP(i) do { } while (0)
 #endif
