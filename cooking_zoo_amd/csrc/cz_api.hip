@@ -217,6 +217,7 @@ struct cz_handle_s {
     bool graphs_enabled = true;    // CZ_GRAPHS=0: cz_step_device_ring launches everything directly
     bool ring_fused = false;       // cz_set_ring_fused: runs of cz_step_device_ring / _many go out as fused launches (outputs in place)
     int64_t n_ring_fused_steps = 0, n_ring_fused_launches = 0;
+    int32_t graph_min_run = 48;    // CZ_GRAPH_MIN_RUN: shorter pieces of a ring run are launched directly (see ring_walk)
     int32_t ring_prefix = 0;       // CZ_RING_PREFIX: steps of a cz_step_device_ring call launched directly in front of its first graph
     size_t zero_copy_bytes = (size_t)256 << 10;   // cz_step: batches whose buffers fit use the pinned device-mapped block (CZ_ZERO_COPY_BYTES)
     cz_stats *d_gather = nullptr;
@@ -355,6 +356,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
 #endif
     if (const char *s = getenv("CZ_WT")) h->wt_override = atoi(s);
     if (const char *s = getenv("CZ_GRAPHS")) h->graphs_enabled = atoi(s) != 0;
+    if (const char *s = getenv("CZ_GRAPH_MIN_RUN")) h->graph_min_run = atoi(s) < 4 ? 4 : atoi(s);
     if (const char *s = getenv("CZ_RING_PREFIX")) h->ring_prefix = atoi(s) < 0 ? 0 : (atoi(s) > 16 ? 16 : atoi(s));
     if (const char *s = getenv("CZ_ZERO_COPY_BYTES")) h->zero_copy_bytes = (size_t)atoll(s);
 #ifdef CZ_ABLATE
@@ -1158,7 +1160,10 @@ static int ring_walk(cz_handle h, int32_t K, const int32_t *d_ring, int64_t stri
         int32_t run = K - k;
         if (run > period - slot) run = period - slot;
         if (run > RING_MAX_GRAPH) run = RING_MAX_GRAPH;
-        if (graphs && run >= RING_MIN_GRAPH + h->ring_prefix) {
+        // Short pieces go out as plain launches: a graph's first kernel starts ~10-16 us after hipGraphLaunch, a directly launched one
+        // after ~3-5 us, and the host enqueues a launch (2.8 us) faster than the device runs it - a 20-step region takes 6.7 us per step
+        // launched directly against 6.85 us replayed (profiles/r05/k20_modes.txt); long runs are replayed (no host work per launch).
+        if (graphs && run >= h->graph_min_run + h->ring_prefix) {
             // Replaying a graph costs the host ~10-16 us before its first kernel starts; a directly launched kernel starts
             // after ~3-5 us.  So the first `ring_prefix` steps of a piece go out as plain launches and keep the GPU busy
             // while the host submits the graph of the rest behind them.

@@ -260,6 +260,10 @@ __device__ __forceinline__ uint4_t load_desc4(const Params &P, uint32_t layout, 
     const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(P.lay_desc), 0, P.L * P.F * 4, 0x00020000);
     return __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(rd, f * 4u, layout * (uint32_t)P.F * 4u, 0));
 }
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) {                       // v_pk_sub_u16: two 16-bit lanes, no borrow across
+    return __builtin_bit_cast(uint32_t, (ushort2_t)(__builtin_bit_cast(ushort2_t, a) - __builtin_bit_cast(ushort2_t, b)));
+}
 template <int OPL, int CPL, int NA, bool F64 = true>
 __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA> &e, const Ctx &cx, Lds<CPL> &s,
                                         const double *lut, uint32_t (&dsc)[OBS_CHUNK], uint32_t submask, double *__restrict__ out /* [A][F] of this env */,
@@ -342,17 +346,18 @@ __device__ __forceinline__ void observe(const Params &P, const Env<OPL, CPL, NA>
             for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) sb[a][k] = *reinterpret_cast<const int32_t *>(subb + 64 * a + (dw[k] >> 16));
+            // A code is (image halfword - subtrahend) >> 3, both multiples of 8 below 2048: two features share a register as 16-bit
+            // halves (v_pk_sub_u16), one 32-bit shift by 3 leaves each code in the low byte of its half, v_perm_b32 gathers the
+            // four bytes of a lane; bytes past F are forced to the padding value by an OR (vector-only: no scalar work per round)
+            const uint32_t p01 = b[0] | (b[1] << 16), p23 = b[2] | (b[3] << 16);
+            const int left = P.F - (int)f;                                                  // features of this lane that exist
+            const uint32_t pad = left >= 4 ? 0u : left <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8u * (uint32_t)left));
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
-                uint32_t w = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    // (features past F: descriptor words of the next row, or 0 behind the table's end -> the padding value)
-                    const uint32_t c = (f + (uint32_t)k < (uint32_t)P.F) ? (((uint32_t)((int)b[k] - sb[a][k]) >> 3) & 0xFFu) : (uint32_t)LUT_ABSENT;
-                    w |= c << (8 * k);
-                }
+                const uint32_t s01 = (uint32_t)sb[a][0] | ((uint32_t)sb[a][1] << 16), s23 = (uint32_t)sb[a][2] | ((uint32_t)sb[a][3] << 16);
+                const uint32_t c01 = pk_sub_u16(p01, s01) >> 3, c23 = pk_sub_u16(p23, s23) >> 3;
                 // (write-through like the float64 rows of a one-step launch: nothing stays dirty until the end-of-kernel write-back)
-                __builtin_amdgcn_raw_buffer_store_b32(w, rc[a], f, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(c23, c01, 0x06040200u) | pad, rc[a], f, 0, 16);
             }
         }
     }

@@ -218,8 +218,9 @@ int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_actions, int64_
 
 /* The same for actions kept in a ring of `action_period` slots (slot s at d_ring + s * action_stride): step k reads slot
  * (first_slot + k) % action_period.  Runs of consecutive slots (cut where the ring wraps and at 256 launches; at least
- * 4 launches long) are captured into HIP graphs on first use, keyed by (first slot, length), and replayed afterwards
- * (no host work per launch, stable kernel-argument memory); shorter pieces are launched directly; identical results.
+ * 48 launches long - CZ_GRAPH_MIN_RUN) are captured into HIP graphs on first use, keyed by (first slot, length), and replayed
+ * afterwards (no host work per launch, stable kernel-argument memory); shorter pieces are launched directly (a graph's first
+ * kernel starts later than a plain launch's, which a short run cannot win back); identical results.
  * At most 64 graphs are kept per handle: keep the runs of a loop aligned to the same slots. */
 int cz_step_device_ring(cz_handle h, int32_t K, const int32_t *d_ring, int64_t action_stride, int32_t action_period,
                         int32_t first_slot, double *d_obs, double *d_rewards, uint8_t *d_terminations, uint8_t *d_truncations);

@@ -210,3 +210,54 @@ def test_ring_runs_with_compact_output_set_on_the_handle():
             assert np.array_equal(bits(table[d_codes.to_host()[:, :, :env.F]]), bits(oo)), phase
         assert np.array_equal(strip(env.get_state()), orc.records), phase
     env.close()
+
+
+@pytest.mark.parametrize("scheme,level,agents,recipes,meta", [CASES[0], CASES[1], CASES[4], CASES[6], CASES[-1]])
+def test_first_observation_as_codes_after_reset_and_set_state(scheme, level, agents, recipes, meta):
+    """cz_observe_compact / cz_observe_device: the compact form of observe() before any step has run - after reset and after
+    set_state - decodes to the float64 observation bit for bit; the padding bytes of a row are 255 and entry 255 of the table
+    is 0.0 (what include/cookingzoo.h promises a consumer that reads whole rows)."""
+    from oracle_binding import VecOracle
+    n = 96
+    env = make(n, level, meta, agents, recipes, scheme)
+    orc = VecOracle.from_vec_env(env)
+    table = env.obs_table()
+    assert table[soa.LUT_ABSENT] == 0.0 and soa.LUT_ABSENT == 255
+    F, Fp = env.F, env.codes_pitch
+    codes = env.reset(return_codes=True)
+    assert codes.shape == (n, agents, Fp) and (codes[:, :, F:] == 255).all()
+    assert np.array_equal(bits(table[codes[:, :, :F]]), bits(orc.reset()))
+    for _ in range(12):
+        acts = np.random.default_rng(1).integers(0, env.n_actions, size=(n, agents), dtype=np.int32)
+        env.step(acts, return_obs=False)
+        oo, *_ = orc.step(acts)
+    assert np.array_equal(bits(table[env.observe_compact()[:, :, :F]]), bits(oo))
+    # into device buffers, both forms at once, for a part of the batch
+    d_obs, d_codes = env.alloc((40, agents, F), np.float64), env.alloc((40, agents, Fp), np.uint8)
+    d_codes.from_host(np.zeros((40, agents, Fp), np.uint8))
+    env.observe_device(d_obs, d_codes, env_begin=17, env_count=40)
+    env.sync()
+    assert np.array_equal(bits(d_obs.to_host()), bits(oo[17:57]))
+    got = d_codes.to_host()
+    assert np.array_equal(bits(table[got[:, :, :F]]), bits(oo[17:57])) and (got[:, :, F:] == 255).all()
+    from cooking_zoo_amd import _native
+    with pytest.raises(_native.NativeError, match="null"):
+        env.observe_device(None, None)
+    env.close()
+
+
+def test_set_layouts_on_a_multi_level_spawning_batch_is_refused():
+    """replacing the whole pool of a multi-level batch with despawn / respawn on would lose the layout -> level map"""
+    env = make(32, ["coop_test", "switch_test"], "example", 2, ["TomatoSalad", "TomatoSalad"], "scheme3", agent_despawn_rate=0.1,
+               agent_respawn_rate=0.2, spawn_seed=1)
+    with pytest.raises(ValueError, match="multi-level"):
+        env.set_layouts(env.layouts[:4])
+    # ... and on the C side a reloaded pool invalidates the spawn tables until cz_set_spawn is called again
+    from cooking_zoo_amd import _native
+    env._upload_layouts()
+    with pytest.raises(_native.NativeError, match="cz_set_spawn"):
+        env.step(np.zeros((32, 2), np.int32))
+    env._set_spawn()
+    env.reset(return_obs=False)
+    env.step(np.zeros((32, 2), np.int32))
+    env.close()

@@ -103,9 +103,9 @@ def make(kernel_sub):
         for k in range(blk.size):
             amap[blk.a + k] = blk.b + k
     # .text: file offset of an address inside the code object
-    sec = subprocess.run([OBJDUMP, "-h", tmp], capture_output=True, text=True).stdout
-    t = re.search(r"\.text\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)", sec)
-    size, vma, off = int(t.group(1), 16), int(t.group(2), 16), int(t.group(4), 16)
+    sec = subprocess.run([OBJDUMP.replace("objdump", "readelf"), "-S", tmp], capture_output=True, text=True).stdout
+    t = re.search(r"\]\s+\.text\s+PROGBITS\s+([0-9a-f]+)\s+([0-9a-f]+)\s+([0-9a-f]+)", sec)
+    vma, off, size = int(t.group(1), 16), int(t.group(2), 16), int(t.group(3), 16)
     os.makedirs(os.path.join(CSRC, "cuts"), exist_ok=True)
     meta = {"kernel": kernel_sub, "static_instructions": len(mn_s), "cuts": {}}
     for i, pos in sorted(marks.items()):
@@ -115,6 +115,7 @@ def make(kernel_sub):
             pos += 1
         addr = ins[amap[pos]][0]
         fo = base + off + (addr - vma)
+        assert vma <= addr < vma + size
         patched = bytearray(blob)
         patched[fo:fo + 4] = S_ENDPGM
         out = os.path.join(CSRC, "cuts", f"libcz_cut_{i}.so")

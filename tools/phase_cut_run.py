@@ -35,4 +35,4 @@ L, h = _native.lib(), env._h
 for k in range(n):
     L.cz_step_device(h, d_ring.ptr + (k % P) * N * A * 4, d_obs.ptr, d_rew.ptr, d_t.ptr, d_u.ptr)
 env.sync()
-os._exit(0)          # (no teardown through a library whose kernels end early)
+env.close()
