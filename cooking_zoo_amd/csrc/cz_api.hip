@@ -351,17 +351,11 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     P.recipe_reward = cfg->recipe_reward; P.recipe_penalty = cfg->recipe_penalty; P.node_reward = cfg->recipe_node_reward;
     P.time_penalty_step = cfg->max_time_penalty / (double)cfg->max_steps;       // cooking_env.py:307
     P.T = 1;
-#ifdef CZ_ABLATE
-    P.stop = -1;
-#endif
     if (const char *s = getenv("CZ_WT")) h->wt_override = atoi(s);
     if (const char *s = getenv("CZ_GRAPHS")) h->graphs_enabled = atoi(s) != 0;
     if (const char *s = getenv("CZ_GRAPH_MIN_RUN")) h->graph_min_run = atoi(s) < 4 ? 4 : atoi(s);
     if (const char *s = getenv("CZ_RING_PREFIX")) h->ring_prefix = atoi(s) < 0 ? 0 : (atoi(s) > 16 ? 16 : atoi(s));
     if (const char *s = getenv("CZ_ZERO_COPY_BYTES")) h->zero_copy_bytes = (size_t)atoll(s);
-#ifdef CZ_ABLATE
-    if (const char *s = getenv("CZ_STOP")) P.stop = atoi(s);      // (the ablation build only: make ablate)
-#endif
 #ifdef CZ_SMALL_ONLY       // diagnostic libraries that carry the small instance only
     if (!(P.D <= 64 && C <= 64)) { fail(nullptr, "cz_create: this diagnostic library holds the small kernel instance only"); cz_destroy(h); return 1; }
     h->kl = launchers_small();
@@ -795,7 +789,7 @@ extern "C" int cz_update_layouts(cz_handle h, int32_t first, int32_t count, cons
     memcpy(st_desc, obs_desc, (size_t)count * Fb);
     // The copy must come after every step issued so far (their envs may still read the old content).  A device-side wait of the
     // copy stream for the handle's stream would do - and slow every step kernel down by a microsecond for as long as it is
-    // pending (a second hardware queue with an outstanding barrier: measured, tools/rot_probe.py).  So the copy is issued
+    // pending (a second hardware queue with an outstanding barrier: measured in round 3, profiles/r03/rot_probe.txt).  So the copy is issued
     // LATER, by whichever call of this handle first finds that those steps have completed (flush_updates), with nothing to
     // wait for on the device.
     HIPCHK(h, hipEventRecord(h->ev_steps_issued, h->stream));

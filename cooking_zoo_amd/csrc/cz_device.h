@@ -80,9 +80,6 @@ struct Params {
     int32_t wt;                    // 1: observation stores are write-through (sc1); chosen per launch by the host
     int32_t walk_touches;          // 1 if carrying an object across cells can change a recipe mark (see cz_load_recipes)
     int32_t wide;                  // 1: wide recipe tables (up to 16 nodes per graph, marks in record words 1 and 7)
-#ifdef CZ_ABLATE
-    int32_t stop, stop_pad;        // ablation build only: phase index after which the kernel returns (CZ_STOP), else -1
-#endif
     // (the argument block: 56 bytes of leading scalars + this struct, within five 64-byte lines; a sixth line costs every launch)
 #ifdef CZ_PROFILE
     unsigned long long *stamps;    // diagnostic build only: [N][8] s_memtime stamps
@@ -91,7 +88,7 @@ struct Params {
     unsigned long long *timeline;  // timeline build only (make timeline): [N][2] entry / exit stamps of this launch's waves, or nullptr
 #endif
 };
-#if !defined(CZ_TIMELINE) && !defined(CZ_ABLATE) && !defined(CZ_PROFILE)
+#if !defined(CZ_TIMELINE) && !defined(CZ_PROFILE)
 static_assert(sizeof(Params) <= 264 && sizeof(Params) % 8 == 0, "argument block: see the note above");
 #endif
 

@@ -17,9 +17,6 @@ namespace cz {
         __builtin_amdgcn_sched_barrier(0);                                                             \
         if (lane == 0 && P.stamps) P.stamps[(size_t)env * 16 + (i)] = _t;                               \
     } while (0)
-#elif defined(CZ_ABLATE)
-// instruction-count ablation build (make ablate): CZ_STOP=i truncates the step after phase i; no stamps, no asm
-#define CZ_STAMP(i) do { if (P.stop == (i)) return; } while (0)
 #elif defined(CZ_MARKERS)
 // marker build (tools/phase_cut.py, never loaded): an assembler comment at every phase boundary and no instruction - if the
 // instruction stream equals the shipped one (tools/isa_diff.py), the comments are positions in the shipped code
@@ -632,9 +629,6 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
     // clock per wave - at its first instruction and behind its last store - and
     // one 16-byte store of lane 0.  No waits are added in between (unlike the phase stamps of `make prof`).
     const uint64_t tl_in = wall_clock64();
-#ifdef CZ_TL_CLOCK
-    const uint64_t tl_cyc_in = __builtin_readcyclecounter();      // s_memtime: the shader clock
-#endif
 #endif
     Params P = P0;
     P.state = e_state; P.actions = e_actions; P.lut = e_lut; P.N = e_N; P.RW = e_RW; P.W = e_W; P.H = e_H; P.D = e_D;
@@ -747,9 +741,6 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
 #ifdef CZ_TIMELINE
         tl_dbg |= o.dbg;
 #endif
-#if defined(CZ_ABLATE)
-        if (Pt.stop == 2 || Pt.stop == 3) return;
-#endif
         CZ_STAMP(4);
         cells_dirty |= dt.cells != 0;
         objs_dirty |= (dt.touched | dt.interacted | dt.moved) != 0;
@@ -843,11 +834,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
             typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
             ull2 v;
             v.x = (tl_in & 0xFFFFFFFFull) | ((unsigned long long)(hw_id & 0xFFFFu) << 32) | ((unsigned long long)tl_dbg << 48);
-#ifdef CZ_TL_CLOCK      // (tools/shader_clock.py: the wave's lifetime in shader-clock cycles instead of the hand-off stamp)
-            v.y = (tl_out & 0xFFFFFFFFull) | ((unsigned long long)(xcc & 15u) << 32) | (((__builtin_readcyclecounter() - tl_cyc_in) & 0xFFFFFFFull) << 36);
-#else
             v.y = (tl_out & 0xFFFFFFFFull) | ((unsigned long long)(xcc & 15u) << 32) | (((tl_seen - tl_in) & 0xFFFFFFFull) << 36);
-#endif
             *reinterpret_cast<ull2 *>(tl + 2 * (size_t)env) = v;
         }
     }

@@ -840,6 +840,13 @@ def main():
     sets["refcrash_cutboard_scheme1"] = lambda: refcrash_set(
         "refcrash_cutboard_scheme1", base_cfg("coexistence_test", 2, ["TomatoLettuceSalad", "CarrotBanana"], scheme="scheme1", max_steps=400),
         REFCRASH_PLAN, args.out)
+    # ... the same class on another level family with four agents (reproducer of profiles/r05/refcrash_histogram_hunt.json)
+    own = lambda stem: (os.path.join(REPO, "cooking_zoo_amd", "utils", "level", stem + ".json"),
+                        os.path.join(REPO, "cooking_zoo_amd", "utils", "meta_files", stem + ".json"))
+    sets["refcrash_cutboard_crowded"] = lambda: refcrash_set(
+        "refcrash_cutboard_crowded", base_cfg(own("crowded_6x5")[0], 4, ["MashedCarrotBanana", "TomatoLettuceOnionSalad", "no_recipe", "AppleWatermelon"],
+                                             scheme="scheme1", max_steps=209, meta=own("crowded_6x5")[1]),
+        [(2028264, "bumper", 110)], args.out)
     # cfg 1: 1 agent, coop_test, TomatoLettuceSalad
     sets["cfg1_coop_1agent"] = lambda: run_set(
         "cfg1_coop_1agent", base_cfg("coop_test", 1, ["TomatoLettuceSalad"]),

@@ -146,23 +146,29 @@ def table(root):
             dur = sorted(dur)[len(dur) // 10: len(dur) - len(dur) // 10] or dur
             rows[i]["launch_us"] = sum(dur) / len(dur) / 1e3
     order = [str(i) for i in sorted(PHASES)] + ["full"]
-    keys = ["SQ_INSTS_SALU", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH"]
-    print("phase table of " + meta.get("kernel", "?") + ": per wave (= env) and launch, cumulative up to the cut, and the phase's own share")
-    print("| ends before | phase that ran last | SALU | VALU | LDS | SMEM | VMEM rd / wr | branch | launch us | phase: SALU + VALU | phase: us |")
+    keys = ["SQ_INSTS_SALU", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"]
+    print(f"# Phase table of cz::{meta.get('kernel', '?')} (one launch per step, 4096 envs, bench workload, warm state) - `bash tools/phase_cut.sh`\n")
+    print("Marker build (assembler comments at the CZ_STAMP boundaries; tools/isa_diff.py: a handful of instructions off the shipped kernel) cut short by\n"
+          "`s_endpgm` at one boundary per library copy; rocprofv3 `--pmc` (two counter sets, 64 launches each) and `--kernel-trace` (2000 direct launches,\n"
+          "trimmed mean) per copy.  Counts are exact and additive: per wave (= env) and launch, what ran up to the boundary, and the phase's own share as\n"
+          "the difference to the row above.  Launch times are NOT additive - a kernel that ends early also ends the contention its later phases would have\n"
+          "caused, and a launch ends with its slowest wave - they say how long a launch takes whose waves all stop there.\n")
+    print("| kernel ends at | last phase that ran | SALU | VALU | LDS | SMEM | VMEM rd / wr | branch | launch us | this phase: SALU + VALU + LDS | + us |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")
     prev = None
     out = {}
     for i in order:
-        if i not in rows:
+        if i not in rows or "SQ_INSTS_SALU" not in rows[i]:
             continue
         r = rows[i]
+        g = lambda k: r.get(k, float("nan"))
         name = "whole kernel" if i == "full" else f"boundary {i}"
-        last = PHASES.get(int(i) - 1 if i != "full" else 7, "-") if i != "0" else "(kernel entry)"
-        own = "" if prev is None else f"{r.get('SQ_INSTS_SALU', 0) - prev.get('SQ_INSTS_SALU', 0):.0f} + {r.get('SQ_INSTS_VALU', 0) - prev.get('SQ_INSTS_VALU', 0):.0f}"
-        own_us = "" if prev is None or "launch_us" not in r or "launch_us" not in prev else f"{r['launch_us'] - prev['launch_us']:.2f}"
-        print(f"| {name} | {last} | " + " | ".join(f"{r.get(k, float('nan')):.0f}" for k in keys[:4]) +
-              f" | {r.get('SQ_INSTS_VMEM_RD', float('nan')):.0f} / {r.get('SQ_INSTS_VMEM_WR', float('nan')):.0f} | {r.get('SQ_INSTS_BRANCH', float('nan')):.0f} | "
-              f"{r.get('launch_us', float('nan')):.2f} | {own} | {own_us} |")
+        last = PHASES[int(i)] if i != "full" else "(behind boundary 7: s_endpgm only)"
+        p0 = prev or {}
+        own = f"{g('SQ_INSTS_SALU') - p0.get('SQ_INSTS_SALU', 0):.0f} + {g('SQ_INSTS_VALU') - p0.get('SQ_INSTS_VALU', 0):.0f} + {g('SQ_INSTS_LDS') - p0.get('SQ_INSTS_LDS', 0):.0f}"
+        own_us = f"{g('launch_us'):.2f}" if prev is None else f"{g('launch_us') - p0.get('launch_us', float('nan')):+.2f}"
+        print(f"| {name} | {last} | " + " | ".join(f"{g(k):.0f}" for k in keys) + f" | {g('SQ_INSTS_VMEM_RD'):.0f} / {g('SQ_INSTS_VMEM_WR'):.0f} | "
+              f"{g('SQ_INSTS_BRANCH'):.0f} | {g('launch_us'):.2f} | {own} | {own_us} |")
         out[i] = r
         prev = r
     json.dump(out, open(os.path.join(root, "phase_table.json"), "w"), indent=1)
