@@ -263,6 +263,10 @@ def run_biased_case(i, kw, seed):
     EVENT_STEPS[0] += ev.steps
     EVENT_STEPS[1] += 1
     env.close()
+    if os.environ.get("CZ_FUZZ_EVENT_LOG"):          # soak runs: the running table after every case (a killed run still leaves it)
+        with open(os.environ["CZ_FUZZ_EVENT_LOG"], "w") as f:
+            f.write(f"event coverage of {EVENT_STEPS[1]} biased cases so far (last: case {i}), {EVENT_STEPS[0]} live env-steps, device == oracle on all of them\n")
+            f.write("".join(f"  {k:20s} {EVENT_TOTALS[k]}\n" for k in EVENTS))
 
 
 def test_zz_biased_runs_reached_the_deep_transitions():

@@ -151,3 +151,54 @@ def test_config4_in_five_lines():
     st = env.stats()
     env.close()
     assert st["env_steps"] == 8192 * 64 and len(env.plan) == 4
+
+
+_RANK_SCRIPT = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, {repo!r})
+from cooking_zoo_amd.distributed import FileRendezvous
+from cooking_zoo_amd.sharded import ShardedVecEnv
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+rv = FileRendezvous({rdzv!r}, rank, world, timeout=120.0)
+env = ShardedVecEnv(301, ["coop_test", "switch_test"], "example", 2, 27, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3",
+                    num_layouts=6, device_ids=[0], world_size=world, rank=rank, rendezvous=rv, agent_despawn_rate=0.05, agent_respawn_rate=0.3,
+                    grace_period=2, spawn_seed=9)
+env.reset(return_obs=False)
+env.barrier()
+env.rollout(120, 4, 0)
+acts = np.random.default_rng(1).integers(0, 5, size=(301, 2), dtype=np.int32)[env.local_begin:env.local_begin + env.local_envs]
+obs, rew, term, trunc = env.step(acts)
+env.barrier()
+np.save({out!r} + f".state{{rank}}.npy", env.get_state())
+np.save({out!r} + f".obs{{rank}}.npy", obs)
+json.dump(dict(stats=env.stats(), per_shard=len(env.stats_per_shard()), comm=env.comm_kind, note=env.comm_note, ranges=env.ranges, plan=env.plan),
+          open({out!r} + f".{{rank}}.json", "w"))
+env.close()
+"""
+
+
+def test_two_processes_one_shard_each_equal_one_handle(tmp_path):
+    """The multi-process form (one process per shard, FileRendezvous between them) - what `bench.py --gpus N` and torchrun start - on the one
+    GPU a test box has: both ranks drive device 0, so the statistics go over the host path (RCCL refuses duplicate devices); states,
+    observations and the statistics of the job must equal one handle over the whole batch, and every rank must report the same totals."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT.format(repo=repo, rdzv=str(tmp_path / "rdzv"), out=str(tmp_path / "out")))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    res = [json.load(open(str(tmp_path / "out") + f".{r}.json")) for r in range(2)]
+    assert res[0]["stats"] == res[1]["stats"] and res[0]["per_shard"] == 2 and res[0]["comm"] == "host" and "share a device" in res[0]["note"]
+    assert res[0]["plan"] == [[0, 151], [151, 150]] and res[1]["ranges"] == [[151, 150]]
+    kw = dict(action_scheme="scheme3", num_layouts=6, agent_despawn_rate=0.05, agent_respawn_rate=0.3, grace_period=2, spawn_seed=9)
+    one = CookingVecEnv(301, ["coop_test", "switch_test"], "example", 2, 27, ["TomatoLettuceSalad", "CarrotBanana"], **kw)
+    one.reset(return_obs=False)
+    one.rollout(120, 4, 0)
+    obs, *_ = one.step(np.random.default_rng(1).integers(0, 5, size=(301, 2), dtype=np.int32))
+    state = np.concatenate([np.load(str(tmp_path / "out") + f".state{r}.npy") for r in range(2)])
+    assert np.array_equal(state, one.get_state())
+    assert np.array_equal(bits(np.concatenate([np.load(str(tmp_path / "out") + f".obs{r}.npy") for r in range(2)])), bits(obs))
+    same_stats(one.stats(), res[0]["stats"])
+    one.close()
