@@ -612,6 +612,8 @@ def worker_body(args, rdzv):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if os.environ.get("CZ_BENCH_DEVICE") is not None:       # test hook: every rank on this device (a one-GPU box running N > 1 ranks; the
+        local_rank = int(os.environ["CZ_BENCH_DEVICE"])     # statistics then go over the host path and the run exits with EXIT_COMM_FAILED)
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used", file=sys.stderr)
     N, K, Wm, R = args.envs, args.steps, args.warmup, max(1, args.repeats)

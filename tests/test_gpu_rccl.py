@@ -78,3 +78,25 @@ def test_two_ranks_on_one_device_agree_on_the_outcome():
         assert "rank 0:" in d["message"] and "rank 1:" in d["message"]
     else:
         assert d["allgather_equals_local_stats"] is True and d["total_env_steps"] > 0
+
+
+def test_bench_two_ranks_on_the_one_device():
+    """`python bench.py --gpus 2` end to end on a one-GPU box: both ranks are put on device 0 (CZ_BENCH_DEVICE), so everything of the multi-rank
+    path runs for real - the launcher, the rendezvous, ShardedVecEnv in its multi-process form, the headline regions between all-rank
+    barriers, BASELINE config 4's shape (2 x 32 768 envs) - except the RCCL exchange between distinct devices, which RCCL refuses here: the
+    statistics come over the host path, the line says so, and the exit code is the communicator-failed one (3), on every rank."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CZ_BENCH_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "CZ_RDZV_DIR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "5",
+                        "--envs", "2048", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 3 and len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 1e6
+    assert "communicator not available" in d["episode_stats_allgather"]["cz_stats_allgather"]
+    assert d["episode_stats_allgather"]["total"]["env_steps"] > 2 * 2048 * 20 * 5
+    c4 = d["config4"]
+    assert c4["envs"] == 65536 and c4["shards"] == [[0, 32768], [32768, 32768]] and c4["value"] > 1e6
