@@ -820,6 +820,10 @@ def worker_body(args, rdzv):
             line["cpu_baseline"] = guarded(cpu_baseline, env)
         emit(line)
     sys.stdout.flush()
+    try:
+        rdzv.barrier()                           # nobody leaves before rank 0 has printed the line (the launcher ends the job with the first failing rank)
+    except Exception:                            # noqa: BLE001
+        pass
     if rc != 0:
         os._exit(rc)                             # a communicator stuck in bring-up cannot be torn down: leave, visibly failed
     senv.close()

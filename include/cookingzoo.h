@@ -18,6 +18,17 @@
  *   | 12..19 four float64 running episode returns (statistics only) | cells (W*H bytes: type | READY<<3 | TOGGLE<<4 | ACTIVE<<5 | WALK<<6) | dyn0[D] (x | y<<8 | class<<16 | flags<<24;
  *   flags: 1 alive, 2 chopped, 4 mashed, 8 free) | dyn1[D] ((plate slot+1) | seq<<8), padded to 16 words.
  * (normative description: cooking_zoo_amd/soa.py)
+ *
+ * WHERE THE REFERENCE RAISES, the step kernels do something defined instead (profiles/r05/deviations.md, generated from the
+ * differential fuzz's histograms by tools/deviations.py):
+ *   - EXECUTE in front of a READY Cutboard with empty content (TypeError, cooking_world.py:162 <- world_objects.py:250-269; reachable
+ *     in scheme1: a mashed Banana on the board is absorbed by a Plate in hand): no-op, the board stays READY
+ *     (tests/golden/refcrash_cutboard_*.npz hold the reference's own outputs past that step);
+ *   - a scheme1 interaction aimed off the grid (IndexError): no-op;
+ *   - max_steps reached while an agent is despawned (IndexError, cooking_env.py:337): the step truncates;
+ *   - a respawn that finds no free cell in 1001 tries, or a candidate beyond the grid (ValueError, parsing.py:159,166): the agent stays
+ *     where it is and cz_spawn_exhausted counts it.
+ * Refused before anything runs: a level with two Switches, action scheme 2, more than 4 agents (the reference's own limits or crashes).
  */
 #ifndef COOKINGZOO_H
 #define COOKINGZOO_H
