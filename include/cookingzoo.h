@@ -253,7 +253,8 @@ int cz_set_ring_fused(cz_handle h, int32_t enabled);
 int64_t cz_ring_fused_steps(cz_handle h, int32_t reset);
 
 /* How many step kernels cz_step_device_ring has replayed from graphs / launched directly on this handle so far
- * (reset != 0: zero both after reading).  bench.py describes its run from these numbers. */
+ * (reset != 0: zero both after reading).  bench.py describes its run from these numbers.  Fused ring runs (cz_set_ring_fused) are
+ * not in either count: cz_ring_fused_steps has theirs. */
 int cz_launch_counts(cz_handle h, int64_t *graph_kernels, int64_t *direct_kernels, int32_t reset);
 
 /* T fused steps in one launch with on-device uniform random actions (counter-based stream keyed by

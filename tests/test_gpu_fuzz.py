@@ -187,6 +187,23 @@ from fuzz_policy import EVENTS, BumperActions, EventCounter   # noqa: E402
 
 EVENT_TOTALS = {k: 0 for k in EVENTS}
 EVENT_STEPS = [0, 0]                      # live env-steps, cases
+# ... and the same per kernel instance (1 slot / 1 cell per lane, 2 / 4, 4 / 16: cz_kernels.h), so that a soak says what each one reached
+INSTANCES = ("small", "large", "huge")
+EVENT_BY_INSTANCE = {n: {k: 0 for k in EVENTS} for n in INSTANCES}
+CASES_BY_INSTANCE = {n: 0 for n in INSTANCES}
+
+
+def instance_of(dims):
+    return "small" if dims.D <= 64 and dims.C <= 64 else "large" if dims.D <= 128 and dims.C <= 256 else "huge"
+
+
+def event_table():
+    lines = [f"event coverage of {EVENT_STEPS[1]} biased cases, {EVENT_STEPS[0]} live env-steps (device == oracle on all of them); "
+             f"cases per kernel instance: " + ", ".join(f"{n} {CASES_BY_INSTANCE[n]}" for n in INSTANCES),
+             f"  {'event':20s} {'all':>10s} " + " ".join(f"{n:>10s}" for n in INSTANCES)]
+    for k in EVENTS:
+        lines.append(f"  {k:20s} {EVENT_TOTALS[k]:10d} " + " ".join(f"{EVENT_BY_INSTANCE[n][k]:10d}" for n in INSTANCES))
+    return "\n".join(lines)
 # the default handful must reach these; a soak (>= 200 cases) must reach every event of fuzz_policy.EVENTS
 CORE_EVENTS = ["pick_up", "put_down", "chop", "plate_add", "static_accepts", "delivery", "marks_changed", "truncation"]
 
@@ -258,24 +275,32 @@ def run_biased_case(i, kw, seed):
         assert np.array_equal(bits(o), bits(oo)) and np.array_equal(bits(r), bits(ro[0])), (ctx, "single step", t)
         assert np.array_equal(te, to[0]) and np.array_equal(tr, uo[0]), (ctx, "single step flags", t)
     assert np.array_equal(strip(env.get_state()), orc.records), ctx
+    inst = instance_of(env.dims)
     for k in EVENTS:
         EVENT_TOTALS[k] += ev.counts[k]
+        EVENT_BY_INSTANCE[inst][k] += ev.counts[k]
+    CASES_BY_INSTANCE[inst] += 1
     EVENT_STEPS[0] += ev.steps
     EVENT_STEPS[1] += 1
     env.close()
     if os.environ.get("CZ_FUZZ_EVENT_LOG"):          # soak runs: the running table after every case (a killed run still leaves it)
         with open(os.environ["CZ_FUZZ_EVENT_LOG"], "w") as f:
-            f.write(f"event coverage of {EVENT_STEPS[1]} biased cases so far (last: case {i}), {EVENT_STEPS[0]} live env-steps, device == oracle on all of them\n")
-            f.write("".join(f"  {k:20s} {EVENT_TOTALS[k]}\n" for k in EVENTS))
+            f.write(f"(running table; last case: {i})\n" + event_table() + "\n")
 
 
 def test_zz_biased_runs_reached_the_deep_transitions():
     """(runs last in the module) the event table of the biased runs; nothing that must be reached stayed at zero"""
     if EVENT_STEPS[1] == 0:
         pytest.skip("no biased case ran in this session")
-    print(f"\nevent coverage of {EVENT_STEPS[1]} biased cases, {EVENT_STEPS[0]} live env-steps (device == oracle on all of them):")
-    for k in EVENTS:
-        print(f"  {k:20s} {EVENT_TOTALS[k]}")
+    print("\n" + event_table())
     must = EVENTS if EVENT_STEPS[1] >= 200 else (CORE_EVENTS if EVENT_STEPS[1] >= 6 else [])
     missing = [k for k in must if EVENT_TOTALS[k] == 0]
     assert not missing, f"never exercised: {missing}"
+    if EVENT_STEPS[1] >= 200:
+        # a soak: every kernel instance on its own reaches the interaction repertoire (its levels have the objects for it);
+        # Switches exist only in levels of the small and the huge instance
+        per = ["pick_up", "put_down", "chop", "plate_add", "static_accepts", "delivery", "marks_changed", "truncation", "despawn", "respawn"]
+        for n in INSTANCES:
+            assert CASES_BY_INSTANCE[n] > 0, f"no case ran on the {n} instance"
+            lacking = [k for k in per if EVENT_BY_INSTANCE[n][k] == 0]
+            assert not lacking, f"the {n} instance never exercised: {lacking}"
