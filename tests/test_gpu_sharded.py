@@ -202,3 +202,27 @@ def test_two_processes_one_shard_each_equal_one_handle(tmp_path):
     assert np.array_equal(bits(np.concatenate([np.load(str(tmp_path / "out") + f".obs{r}.npy") for r in range(2)])), bits(obs))
     same_stats(one.stats(), res[0]["stats"])
     one.close()
+
+
+def test_rotate_layouts_fans_out_to_every_shard():
+    """`rotate_layouts` on a ShardedVecEnv: every shard runs the single handle's rotation with the same seed (its own producer process, the
+    same refills at the same step numbers), so the batch sees what ONE handle that rotates sees - fresh layouts included"""
+    pos = ("coop_test", "example", 2, 9, ["TomatoLettuceSalad", "CarrotBanana"])
+    kw = dict(action_scheme="scheme3", num_layouts=8, layout_seed=2)
+    n = 120
+    one, many = CookingVecEnv(n, *pos, **kw), ShardedVecEnv(n, *pos, device_ids=[0, 0], **kw)
+    try:
+        one.reset(return_obs=False); many.reset(return_obs=False)
+        one.rotate_layouts(40, groups=2, seed=7, prefetch=2)
+        many.rotate_layouts(40, groups=2, seed=7, prefetch=2)
+        for k in range(30):                                            # 600 steps: a dozen switches, as many refills
+            one.rollout(20, 5, 20 * k); many.rollout(20, 5, 20 * k)
+        one.sync(); many.sync()
+        assert np.array_equal(one.get_state(), many.get_state())
+        ev1, evm = one.rotation_events, many.rotation_events
+        assert len(ev1) == len(evm) > 10 and [e[:2] for e in ev1] == [e[:2] for e in evm]
+        assert sum(1 for e in ev1 if e[1] == "layouts") >= 5                # the pool really was refreshed under the running batch
+        same_stats(one.stats(), many.stats())
+    finally:
+        one.stop_rotation(); many.stop_rotation()
+        one.close(); many.close()
