@@ -410,7 +410,10 @@ struct StepOut {
 };
 
 // One accumulated_step (cooking_env.py:243-269) of one env held in registers.
-template <int OPL, int CPL, int NA, int SCHEME>
+// HINT (the fused instances): the reset pass and the end of an episode are laid out off the fall-through path - one step in max_steps + 1
+// takes them; in the one-step kernels the same hint cost the launches under a cooking policy 1.5 % (profiles/r05/ab_experiments.txt)
+#define CZ_RARE(hint, x) ((hint) ? __builtin_expect(!!(x), 0) : !!(x))
+template <int OPL, int CPL, int NA, int SCHEME, bool HINT = false>
 __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<OPL, CPL, NA> &e, const Ctx &cx, uint32_t acts,
                                          int64_t env_global, uint32_t &rowv, Lds<CPL> &lds, uint32_t (&dsc)[OBS_CHUNK], Dirty &dt, StepOut &o) {
     using O = Ops<OPL, CPL, NA, SCHEME>;
@@ -422,7 +425,7 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
     // P.auto_reset: bit 0 = next-step auto-reset, bit 1 = agent despawn / respawn is on (cz_set_spawn)
     const bool spawning = (P.auto_reset & 2) != 0;
     const SpawnCfg *const spawn_cfg = reinterpret_cast<const SpawnCfg *>(reinterpret_cast<const char *>(P.lut) + SPAWN_CFG_OFFSET);
-    if (e.status & ST_DONE) {
+    if (CZ_RARE(HINT, (e.status & ST_DONE) != 0u)) {
         o.header = true;
         if (P.auto_reset & 1) {
             // next-step autoreset: reset() of cooking_env.py:178-210 from the layout pool
@@ -592,7 +595,7 @@ __device__ __forceinline__ void step_env(const Params &P, unsigned kp_off, Env<O
     }
     o.term = done ? 1u : 0u;
     o.trunc = truncated ? 1u : 0u;
-    if (done || truncated) {
+    if (CZ_RARE(HINT, done || truncated)) {
         e.status |= ST_DONE | (done ? ST_TERM : 0u) | (truncated ? ST_TRUNC : 0u);
         o.finished = true;
         o.header = true;
@@ -737,7 +740,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         } else acts = action_hash(Pt.seed, env_global, lane & 3, Pt.step0 + (uint32_t)t, SCHEME == 3 ? 5u : 8u);
         Dirty dt{};
         StepOut o;
-        step_env<OPL, CPL, NA, SCHEME>(Pt, (unsigned)offsetof(StepArgsMirror, p), e, cx, acts, env_global, rowv, lds, dsc, dt, o);
+        step_env<OPL, CPL, NA, SCHEME, FUSED>(Pt, (unsigned)offsetof(StepArgsMirror, p), e, cx, acts, env_global, rowv, lds, dsc, dt, o);
 #ifdef CZ_TIMELINE
         tl_dbg |= o.dbg;
 #endif
@@ -754,7 +757,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         // trip (~1 us after a launch boundary) used to make exactly these waves the last ones of a launch in which nobody acts.
         uint32_t su_old = 0u;
         double sf_old = 0.0, ret_done = 0.0;
-        if (o.finished) {
+        if (CZ_RARE(FUSED, o.finished)) {
             const uint32_t *su = kp->stat_u + (size_t)env * SU_WORDS;
             const double *sf = kp->stat_f + (size_t)env * SF_WORDS;
             su_old = ldg<uint32_t>(su, ((uint32_t)lane & 15u) * 4u);
@@ -772,7 +775,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
         // (the compact path's descriptor words were fetched long ago; waiting for them HERE costs nothing, while behind the
         // stores below the same wait would also stand for those stores' acknowledgement - one counter for loads and stores)
         if (CODES) {
-            if (cpre.layout != e.layout) {                 // a reset pass has moved the env to another layout
+            if (CZ_RARE(FUSED, cpre.layout != e.layout)) {                 // a reset pass has moved the env to another layout
                 cpre.layout = e.layout;
 #pragma unroll
                 for (int r = 0; r < CODES_PREFETCH; ++r) cpre.d[r] = load_desc4(Pt, e.layout, 256u * r + 4u * (uint32_t)lane);
@@ -809,7 +812,7 @@ __device__ __forceinline__ void step_kernel(uint32_t *e_state, const int32_t *e_
             observe<OPL, CPL, NA, !CODES_ONLY>(Pt, e, cx, lds, lut, dsc, submask, obs_row, img_objs, img_cells, codes, CODES ? &cpre : nullptr);
             img_objs = false; img_cells = false;
         }
-        if (o.finished) {                      // (the state is still that of the finished episode: the reset is the next pass)
+        if (CZ_RARE(FUSED, o.finished)) {      // (the state is still that of the finished episode: the reset is the next pass)
             uint32_t *su = kp->stat_u + (size_t)env * SU_WORDS;
             double *sf = kp->stat_f + (size_t)env * SF_WORDS;
             const uint32_t a_of = (uint32_t)lane - SU_COMPLETED0;               // lane SU_COMPLETED0 + a: recipe a completed?
