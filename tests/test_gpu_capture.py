@@ -4,7 +4,6 @@ times, must leave state and outputs bit for bit what the same launches leave whe
 staged (cz_update_layouts' copy is deferred, never issued from inside the capture).  Reference semantics of every captured step:
 cooking_env.py:243-288."""
 import ctypes as C
-import time
 
 import numpy as np
 import pytest
