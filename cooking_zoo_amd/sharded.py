@@ -215,7 +215,8 @@ class ShardedVecEnv:
         self.comm_kind, self.comm_note = "rccl", f"RCCL all-gather of one cz_stats per shard over {G} shard(s)"
 
     def stats_per_shard(self) -> List[Dict]:
-        """one statistics dict per shard OF THE WHOLE JOB, in shard order (on every process)"""
+        """one statistics dict per shard OF THE WHOLE JOB, in shard order (on every process).  COLLECTIVE in the multi-process form: every
+        process has to call it at the same point of its program (it is an all-gather - RCCL's, or the rendezvous' on the host path)."""
         G = len(self.plan)
         if self.comm_kind == "rccl":
             def gather(i, env):
@@ -230,7 +231,8 @@ class ShardedVecEnv:
         return [st for part in every for st in part]
 
     def stats(self) -> Dict:
-        """episode statistics of the whole batch: the shards' cz_stats summed in shard order (bitwise reproducible float64)"""
+        """episode statistics of the whole batch: the shards' cz_stats summed in shard order (bitwise reproducible float64).  Collective
+        like `stats_per_shard`."""
         return czd.reduce_stats(self.stats_per_shard())
 
     def reset_stats(self):
