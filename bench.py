@@ -595,11 +595,13 @@ def timed_regions(senv, K, R, ring, outs, first_slot_of):
     replay), stream sync; -> (elapsed seconds, env-steps executed by this process's shards) per region"""
     elapsed, steps_done = [], []
     period = ring.leading[0]
+    run = senv.ring_runner(K, ring, period, *outs)               # addresses and strides resolved once: the region holds launches + sync
     for r in range(R):
         s0 = sum(st["env_steps"] for st in senv._each(lambda i, env: env.stats()))
+        slot = first_slot_of(r)
         senv.barrier()                                           # stream sync + all-rank barrier
         t0 = time.perf_counter()
-        senv.step_device_ring_sync(K, ring, period, first_slot_of(r), *outs)
+        run(slot)
         elapsed.append(time.perf_counter() - t0)
         senv.barrier()
         steps_done.append(sum(st["env_steps"] for st in senv._each(lambda i, env: env.stats())) - s0)   # (auto-reset passes are not counted)

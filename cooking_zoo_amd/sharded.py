@@ -307,6 +307,27 @@ class ShardedVecEnv:
             env.sync()
         self._each(run)
 
+    def ring_runner(self, K, d_ring, action_period, d_obs, d_rewards, d_term, d_trunc):
+        """-> `run(first_slot)`: `step_device_ring_sync` with everything that does not change between calls resolved once (buffer
+        addresses, strides, the bound C functions) - for loops that issue short runs back to back, where the Python work per call
+        (a few microseconds) is a visible part of a 100 us region"""
+        from cooking_zoo_amd.vec_env import _dev_ptr as p
+        P, L = self._part, _native.lib()
+        fixed = [(env, env._h, (int(K), p(P(d_ring, i)), env.num_envs * env.num_agents, int(action_period)),
+                  (p(P(d_obs, i)), p(P(d_rewards, i)), p(P(d_term, i)), p(P(d_trunc, i)))) for i, env in enumerate(self.shards)]
+        ring, sync, check = L.cz_step_device_ring, L.cz_sync, _native.check
+
+        def one(i, env, first_slot):
+            _, h, a, o = fixed[i]
+            check(h, ring(h, *a, first_slot, *o))
+            check(h, sync(h))
+            env._advance(a[0])
+
+        if len(fixed) == 1:
+            env0 = fixed[0][0]
+            return lambda first_slot: one(0, env0, int(first_slot))
+        return lambda first_slot: self._each(lambda i, env: one(i, env, int(first_slot)))
+
     def ring_prepare(self, K, d_ring, action_period, first_slot, d_obs, d_rewards, d_term, d_trunc):
         """build the HIP graphs of such a run up front (nothing is stepped)"""
         P = self._part

@@ -82,6 +82,10 @@ def test_shards_on_one_device_equal_one_handle(case, devices):
     many.ring_prepare(30, am, T, 5, *om)
     one.step_device_ring(30, a1, n * A, T, 5, *o1)
     many.step_device_ring(30, am, T, 5, *om)
+    run = many.ring_runner(7, am, T, *om)                              # (launches + sync with the addresses resolved once)
+    for first in (35, 42):
+        one.step_device_ring(7, a1, n * A, T, first, *o1)
+        run(first)
     one.sync(); many.sync()
     for x, y in zip(o1, om):
         assert np.array_equal(x.to_host().view(np.uint8), y.to_host().view(np.uint8))
