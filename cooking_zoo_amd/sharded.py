@@ -198,6 +198,8 @@ class ShardedVecEnv:
                 done.set()
             threading.Thread(target=wait_all, daemon=True).start()
             mine = "" if done.wait(timeout=deadline) else "timed out"
+            if pools is not self._pools:
+                pools[0].shutdown(wait=False)                 # (the helper thread of a single local shard)
             mine = mine or "; ".join(f"shard {self.shard_ids[i]}: {m}" for i, m in sorted(box.items()) if m)
         else:
             mine = "rank 0 could not create an RCCL unique id (librccl missing?)"
