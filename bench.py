@@ -101,7 +101,12 @@ def cpu_baseline(env, seconds_target=15.0):
     reps = int(min(max(seconds_target / max(dt1, 1e-3), 1), 2000))
     dt = run_all(reps, 2)
     total = cores * envs_per_thread * T * reps
-    out = {"value": total / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:                                             # noqa: BLE001
+        pass
+    out = {"value": total / dt, "unit": "env-steps/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
            "sample": f"oracle/cz_oracle.c, {cores} threads x {envs_per_thread} envs x {T * reps} steps of the bench "
                      f"workload incl. obs encode ({total} env-steps in {dt:.1f} s); one thread alone: {single:.0f} env-steps/s"}
     ref = reference_python_timing()
