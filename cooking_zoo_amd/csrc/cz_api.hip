@@ -491,11 +491,12 @@ extern "C" int cz_set_spawn(cz_handle h, double despawn_rate, double respawn_rat
                             const uint8_t *spawn_y, const int32_t *n_y) {
     if (!h) return fail(nullptr, "null handle");
     const bool on = despawn_rate > 0.0 || respawn_rate > 0.0;
-    if (despawn_rate < 0.0 || respawn_rate < 0.0 || grace_period < 0 || grace_period > SPAWN_MAX_GRACE)
-        return fail(h, "cz_set_spawn: rates must be >= 0 and 0 <= grace_period <= %d (five bits per agent in the record's status word)", SPAWN_MAX_GRACE);
+    if (despawn_rate < 0.0 || respawn_rate < 0.0 || grace_period < 0 || (uint32_t)grace_period > spawn_max_grace(h->P.A))
+        return fail(h, "cz_set_spawn: rates must be >= 0 and 0 <= grace_period <= %u for %d agent(s) (20 bits of the record's status word hold the "
+                       "countdowns of all agents)", spawn_max_grace(h->P.A), h->P.A);
     SpawnCfg cfg;
     memset(&cfg, 0, sizeof cfg);
-    cfg.seed = seed; cfg.despawn_rate = despawn_rate; cfg.respawn_rate = respawn_rate; cfg.grace_period = (uint32_t)grace_period;
+    cfg.seed = seed; cfg.despawn_rate = despawn_rate; cfg.respawn_rate = respawn_rate; cfg.grace_period = (uint32_t)grace_period | (spawn_grace_bits((uint32_t)grace_period, h->P.A) << 24);
     std::vector<uint8_t> areas, levels;
     if (on) {
         if (!h->P.lay_init) return fail(h, "cz_set_spawn: load the layout pool first (the spawn areas are looked up by layout)");

@@ -141,7 +141,7 @@ enum : uint32_t { LC_GROUPS = 0, LC_ACTIVE = 1 };
 // draw from a counter-based stream keyed by (seed, global env id, episode << 32 | t, agent, draw index) instead - the same
 // function as cooking_zoo_amd/spawn.py `uniform` - so results depend neither on the batch size nor on the sharding nor on how
 // the steps are launched (one per launch, fused).  The record's status word carries one "despawned" bit per agent
-// (bit 8 + a) and five bits of grace countdown each (from bit 12 + 5 a).  The parameters live in device memory behind the
+// (bit 8 + a) and a grace countdown each (from bit 12; field width: spawn_grace_bits).  The parameters live in device memory behind the
 // quotient table.
 struct SpawnCfg {
     uint64_t seed;
@@ -160,11 +160,16 @@ constexpr uint32_t SPAWN_CFG_OFFSET = 256 * 8 + 64 * 4;      // bytes behind Par
 // which word of which recipe row it holds (load_recipe_rows): 8 r | 4 i << 8 for word i of the env's r-th recipe
 constexpr uint32_t COORD_TABLE_OFFSET = SPAWN_CFG_OFFSET + 56, ROWSEL_TABLE_OFFSET = COORD_TABLE_OFFSET + 1024 * 4;
 constexpr uint32_t LUT_BLOCK_BYTES = ROWSEL_TABLE_OFFSET + 64 * 4;
-// status word: bit 8 + a = agent a is despawned; bits 12 + 5 a .. 16 + 5 a = its grace countdown
-constexpr int SPAWN_GONE0 = 8, SPAWN_GRACE0 = 12, SPAWN_GRACE_BITS = 5, SPAWN_MAX_GRACE = 31;
-__host__ __device__ inline uint32_t spawn_initial_status(uint32_t grace_period, int n_agents) {   // everybody present, grace running
+// status word: bit 8 + a = agent a is despawned; from bit 12: one grace countdown per agent, `bits` wide - 5 bits while the grace period
+// is at most 31 (the layout every fixture has), else 20 / n_agents bits (one agent 20, two 10, three 6; four agents stay at 5).
+// SpawnCfg::grace_period carries the period in its low 24 bits and the field width in bits 24..31.
+constexpr int SPAWN_GONE0 = 8, SPAWN_GRACE0 = 12;
+__host__ __device__ inline uint32_t spawn_grace_bits(uint32_t grace_period, int n_agents) { return grace_period <= 31u ? 5u : 20u / (uint32_t)n_agents; }
+__host__ __device__ inline uint32_t spawn_max_grace(int n_agents) { const uint32_t b = 20u / (uint32_t)n_agents; return b > 5u ? (1u << b) - 1u : 31u; }
+__host__ __device__ inline uint32_t spawn_initial_status(uint32_t packed_grace, int n_agents) {   // everybody present, grace running
+    const uint32_t grace = packed_grace & 0xFFFFFFu, bits = packed_grace >> 24;
     uint32_t st = 0;
-    for (int a = 0; a < n_agents; ++a) st |= grace_period << (SPAWN_GRACE0 + SPAWN_GRACE_BITS * a);
+    for (int a = 0; a < n_agents; ++a) st |= grace << (SPAWN_GRACE0 + bits * a);
     return st;
 }
 __host__ __device__ inline uint64_t spawn_mix(uint64_t x) {                      // splitmix64 finaliser
@@ -726,10 +731,11 @@ struct Ops {
         const uint64_t seed = cfg->seed, key = ((uint64_t)e.episode << 32) | (uint64_t)e.t;
         const double despawn_rate = cfg->despawn_rate, respawn_rate = cfg->respawn_rate;
         uint32_t st = e.status, gone = 0u;
+        const uint32_t packed_grace = cfg->grace_period, gbits = packed_grace >> 24, gmask = (1u << gbits) - 1u;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            const int gsh = SPAWN_GRACE0 + SPAWN_GRACE_BITS * a;
-            if ((st >> gsh) & 31u) { st -= 1u << gsh; continue; }                    // agent_grace_period[i] -= 1
+            const uint32_t gsh = (uint32_t)SPAWN_GRACE0 + gbits * (uint32_t)a;
+            if ((st >> gsh) & gmask) { st -= 1u << gsh; continue; }                  // agent_grace_period[i] -= 1
             const bool despawned = (st >> (SPAWN_GONE0 + a)) & 1u;
             if (!despawned) {
                 const int n_active = NA - __popc((st >> SPAWN_GONE0) & 0xFu);
@@ -744,7 +750,7 @@ struct Ops {
                 // not, itself included - stands on (generate_location: up to 1001 tries; the reference raises ValueError when
                 // they are used up or a candidate lies beyond the grid, here such candidates are skipped, the agent comes
                 // back where it stood and the handle counts the event: cz_spawn_exhausted)
-                st = (st & ~(1u << (SPAWN_GONE0 + a))) | (cfg->grace_period << gsh);
+                st = (st & ~(1u << (SPAWN_GONE0 + a))) | ((packed_grace & 0xFFFFFFu) << gsh);
                 typedef const __attribute__((address_space(4))) uint8_t *kbytes;
                 const uint32_t stride = cfg->stride, level = ((kbytes)cfg->level_of_layout)[e.layout];
                 const kbytes blk = (kbytes)cfg->areas + (size_t)(level * (uint32_t)MAX_AGENTS + (uint32_t)a) * (4u + 2u * stride);

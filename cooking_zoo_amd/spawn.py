@@ -128,25 +128,34 @@ class SpawnBook:
 
 
 # ---- the device's encoding of this bookkeeping in record word W_STATUS (csrc/cz_device.h SPAWN_*): bit 8 + a = agent a is
-# despawned, bits 12 + 5 a .. 16 + 5 a = its grace countdown
-SPAWN_GONE0, SPAWN_GRACE0, SPAWN_GRACE_BITS, SPAWN_MAX_GRACE = 8, 12, 5, 31
+# despawned; from bit 12 one grace countdown per agent, `bits` wide: 5 while the grace period is at most 31, else 20 // num_agents
+SPAWN_GONE0, SPAWN_GRACE0 = 8, 12
 
 
-def status_bits(active, grace):
-    """[N, A] bool active, [N, A] int grace -> uint32 [N] to be or-ed into the status word"""
+def grace_bits(grace_period, num_agents):
+    return 5 if int(grace_period) <= 31 else 20 // int(num_agents)
+
+
+def max_grace(num_agents):
+    b = 20 // int(num_agents)
+    return (1 << b) - 1 if b > 5 else 31
+
+
+def status_bits(active, grace, bits=5):
+    """[N, A] bool active, [N, A] int grace -> uint32 [N] to be or-ed into the status word (`bits`: grace_bits(grace_period, A))"""
     out = np.zeros(active.shape[0], dtype=np.uint32)
     for a in range(active.shape[1]):
         out |= (~active[:, a]).astype(np.uint32) << np.uint32(SPAWN_GONE0 + a)
-        out |= grace[:, a].astype(np.uint32) << np.uint32(SPAWN_GRACE0 + SPAWN_GRACE_BITS * a)
+        out |= grace[:, a].astype(np.uint32) << np.uint32(SPAWN_GRACE0 + bits * a)
     return out
 
 
-def decode_status(status, num_agents):
+def decode_status(status, num_agents, bits=5):
     """uint32 [N] status words -> (active [N, A] bool, grace [N, A] int64)"""
     status = np.asarray(status, dtype=np.uint32)
     active = np.empty((status.shape[0], num_agents), dtype=bool)
     grace = np.empty((status.shape[0], num_agents), dtype=np.int64)
     for a in range(num_agents):
         active[:, a] = ((status >> np.uint32(SPAWN_GONE0 + a)) & np.uint32(1)) == 0
-        grace[:, a] = (status >> np.uint32(SPAWN_GRACE0 + SPAWN_GRACE_BITS * a)) & np.uint32(31)
+        grace[:, a] = (status >> np.uint32(SPAWN_GRACE0 + bits * a)) & np.uint32((1 << bits) - 1)
     return active, grace

@@ -112,9 +112,9 @@ class SpawnView:
         self._episode = None
 
     def refresh(self, reset=False):
-        from cooking_zoo_amd.spawn import decode_status
+        from cooking_zoo_amd.spawn import decode_status, grace_bits
         recs = self._env.get_state()
-        active, grace = decode_status(recs[:, soa.W_STATUS], self._env.num_agents)
+        active, grace = decode_status(recs[:, soa.W_STATUS], self._env.num_agents, grace_bits(self._env._spawn_cfg[2], self._env.num_agents))
         episode = recs[:, soa.W_EPISODE].copy()
         same = (not reset) and self._episode is not None
         self.changed = (active != self.active) & (episode == self._episode)[:, None] if same else np.zeros_like(active)

@@ -147,7 +147,8 @@ int64_t cz_layout_updates(cz_handle h);
  * global env id, episode << 32 | t, agent, draw index) (cz_spawn_uniform is the host mirror), so results depend neither on the
  * batch size nor on the sharding nor on the launch form; tests/golden/spawn_keyed_*.npz are trajectories of the unmodified
  * reference functions fed with exactly these draws.  The record's status word carries a "despawned" bit per agent (bit 8 +
- * agent) and a 5-bit grace countdown each (from bit 12 + 5 * agent).  A despawned agent does not act (whatever its action
+ * agent) and a grace countdown each from bit 12 on: 5 bits wide while grace_period <= 31, else 20 / num_agents bits (so grace_period may be
+ * up to 1023 for two agents, 63 for three, 31 for four; the reference takes any int, parsing.py:142).  A despawned agent does not act (whatever its action
  * says), is reported truncated in the step it leaves, and stays in the world as an obstacle; an agent that holds something stays.
  * TAKES EFFECT WITH THE NEXT STEP: worlds reset from then on start with everybody present and the grace period running
  * (parsing.py:142); episodes that are already running continue with whatever their status words hold (grace 0 unless the

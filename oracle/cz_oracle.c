@@ -765,8 +765,10 @@ typedef struct czo_spawn {
     const int32_t *xs, *ys;           /* [n_levels][num_agents][stride]: X_POSITION / Y_POSITION of the level file's AGENTS entries */
 } czo_spawn;
 
-/* status word: bit 8 + a = agent a is despawned (not in world.active_agents), bits 12 + 5 a .. = world.agent_grace_period[a] */
-enum { SPAWN_GONE0 = 8, SPAWN_GRACE0 = 12, SPAWN_GRACE_BITS = 5 };
+/* status word: bit 8 + a = agent a is despawned (not in world.active_agents); from bit 12 world.agent_grace_period[a], `bits` wide each:
+   5 bits while the grace period is at most 31, else 20 / A bits (cz_device.h spawn_grace_bits) */
+enum { SPAWN_GONE0 = 8, SPAWN_GRACE0 = 12 };
+static uint32_t spawn_grace_bits(int32_t grace_period, int A) { return grace_period <= 31 ? 5u : 20u / (uint32_t)A; }
 
 /* the keyed stream: splitmix64 finaliser over (seed, global env id), (episode << 32 | t), (agent, draw index) -> [0, 1) */
 static uint64_t spawn_mix(uint64_t x)
@@ -811,9 +813,10 @@ static int generate_location(const World *w, const czo_spawn *sp, int level, int
 static uint32_t handle_agent_spawn(World *w, const czo_spawn *sp, uint32_t *status, int level, uint64_t env_global, uint64_t key)
 {
     uint32_t st = *status, gone = 0;
+    const uint32_t gbits = spawn_grace_bits(sp->grace_period, w->A), gmask = (1u << gbits) - 1u;
     for (int i = 0; i < w->A; ++i) {
-        const int gsh = SPAWN_GRACE0 + SPAWN_GRACE_BITS * i;
-        if ((st >> gsh) & 31u) { st -= 1u << gsh; continue; }             /* agent_grace_period[i] -= 1 */
+        const uint32_t gsh = SPAWN_GRACE0 + gbits * (uint32_t)i;
+        if ((st >> gsh) & gmask) { st -= 1u << gsh; continue; }           /* agent_grace_period[i] -= 1 */
         int n_active = 0;
         for (int j = 0; j < w->A; ++j) n_active += !((st >> (SPAWN_GONE0 + j)) & 1u);
         const int active = !((st >> (SPAWN_GONE0 + i)) & 1u);
@@ -835,7 +838,7 @@ static uint32_t handle_agent_spawn(World *w, const czo_spawn *sp, uint32_t *stat
 static uint32_t spawn_initial_status(const czo_spawn *sp, int A)     /* load_level.py:67-68, parsing.py:142 */
 {
     uint32_t st = 0;
-    for (int a = 0; a < A; ++a) st |= (uint32_t)sp->grace_period << (SPAWN_GRACE0 + SPAWN_GRACE_BITS * a);
+    for (int a = 0; a < A; ++a) st |= (uint32_t)sp->grace_period << (SPAWN_GRACE0 + spawn_grace_bits(sp->grace_period, A) * (uint32_t)a);
     return st;
 }
 

@@ -227,3 +227,53 @@ def test_spawning_batches_match_the_oracle_rule(levels, meta, agents, recipes, s
         assert env.spawn_exhausted() > 0
     env.close()
     [p.close() for p in parts]
+
+
+@pytest.mark.parametrize("agents,grace,level,meta,recipes", [
+    (2, 200, "coop_test", "example", ["TomatoLettuceSalad", "CarrotBanana"]),
+    (3, 63, "crowded_6x5", "crowded_6x5", ["TomatoSalad", "TomatoLettuceSalad", "MashedCarrotBanana"]),
+    (1, 5000, "coop_test", "example", ["TomatoSalad"]),
+])
+def test_grace_periods_beyond_31(agents, grace, level, meta, recipes):
+    """the reference takes any grace_period (cooking_env.py:28, parsing.py:142).  The status word has 20 bits for the countdowns of all
+    agents: 5 bits each while the period is at most 31 (the layout of every fixture), else 20 / A bits each - 1023 steps for two agents,
+    63 for three, any practical value for one.  Device vs the oracle's rule, and the view the env gives of the countdowns."""
+    from cooking_zoo_amd.spawn import decode_status, grace_bits, max_grace
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    from oracle_binding import VecOracle
+    assert grace > 31 and grace <= max_grace(agents)
+    n = 128
+    kw = dict(action_scheme="scheme3", num_layouts=4, agent_despawn_rate=0.3, agent_respawn_rate=0.5, grace_period=grace, spawn_seed=3)
+    env = CookingVecEnv(n, level, meta, agents, 400, recipes, **kw)
+    orc = VecOracle.from_vec_env(env)
+    assert np.array_equal(bits(env.reset()), bits(orc.reset()))
+    b = grace_bits(grace, agents)
+    _, g0 = decode_status(env.get_state()[:, soa.W_STATUS], agents, b)
+    assert (g0 == grace).all() and (env.spawn.grace == grace).all()
+    rng = np.random.default_rng(2)
+    for t in range(12):
+        acts = rng.integers(0, 5, size=(n, agents), dtype=np.int32)
+        og, *_ = env.step(acts)
+        oo, *_ = orc.step(acts)
+        assert np.array_equal(bits(og), bits(oo)) and np.array_equal(strip(env.get_state()), orc.records), t
+    assert (env.spawn.grace == grace - 12).all()
+    T = min(grace + 40, 380)
+    env.rollout(T, 4, 100); env.sync()
+    orc.rollout(T, 4, 100, want_obs=False)
+    assert np.array_equal(strip(env.get_state()), orc.records)
+    if agents > 1:
+        # somebody has left and come back by now: its countdown was restarted, a value beyond what five bits hold lives in the record
+        _, g = decode_status(orc.records[:, soa.W_STATUS], agents, b)
+        assert (g > 31).any() and (g <= grace).all()
+    env.close()
+
+
+def test_grace_period_beyond_the_field_is_refused():
+    from cooking_zoo_amd import _native
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    with pytest.raises(_native.NativeError, match="grace_period <= 31 for 4 agent"):
+        CookingVecEnv(8, "crowded_6x5", "crowded_6x5", 4, 40, RECIPES, action_scheme="scheme3", num_layouts=2, agent_despawn_rate=0.1,
+                      agent_respawn_rate=0.1, grace_period=32)
+    with pytest.raises(_native.NativeError, match="grace_period <= 1023 for 2 agent"):
+        CookingVecEnv(8, "coop_test", "example", 2, 40, ["TomatoSalad", "TomatoSalad"], action_scheme="scheme3", num_layouts=2,
+                      agent_despawn_rate=0.1, agent_respawn_rate=0.1, grace_period=1024)

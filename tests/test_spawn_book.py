@@ -120,3 +120,17 @@ def test_batched_env_with_spawning_is_shard_invariant_and_consistent():
     assert n_desp > 50
     whole.close()
     [p.close() for p in parts]
+
+
+def test_grace_field_width_follows_the_period_and_the_agent_count():
+    """status-word layout of the countdowns (csrc/cz_device.h spawn_grace_bits): 5 bits each while the period is at most 31 - what every
+    fixture holds -, else 20 // A bits each; encode / decode round-trip at both widths"""
+    from cooking_zoo_amd.spawn import decode_status, grace_bits, max_grace, status_bits
+    assert [grace_bits(g, a) for g, a in ((0, 4), (31, 2), (32, 2), (200, 2), (40, 3), (5000, 1))] == [5, 5, 10, 10, 6, 20]
+    assert [max_grace(a) for a in (1, 2, 3, 4)] == [(1 << 20) - 1, 1023, 63, 31]
+    rng = np.random.default_rng(0)
+    for A, bits in ((2, 5), (2, 10), (3, 6), (4, 5), (1, 20)):
+        active = rng.random((50, A)) < 0.5
+        grace = rng.integers(0, 1 << bits, size=(50, A))
+        a2, g2 = decode_status(status_bits(active, grace, bits), A, bits)
+        assert np.array_equal(a2, active) and np.array_equal(g2, grace)
