@@ -295,6 +295,61 @@ def leg_closed_loop_compact(env, d_rew, d_term, d_trunc):
                                        "HIP events around graph replays; algorithmic bytes with 1 byte per feature", "k_step<1,1,2,3,3>")}
 
 
+def leg_closed_loop_captured(env, d_obs, d_rew, d_term, d_trunc):
+    """The closed loop as a FRAMEWORK would run it: [policy kernel -> cz_step_device] captured into a graph of the CALLER - raw
+    hipStreamBeginCapture on a stream handed to cz_set_stream (what torch.cuda.graph does underneath) - and replayed; the library's own
+    cz_probe_closed_loop (leg `closed_loop`) is the same loop captured inside the library.  tests/test_gpu_capture.py checks that the
+    replays are bit for bit the eager loop."""
+    from cooking_zoo_amd import _native
+    L, h = _native.lib(), env._h
+    rccl_path, hip_path = C.create_string_buffer(512), C.create_string_buffer(512)
+    L.cz_runtime_paths(rccl_path, hip_path, 512)
+    hip = C.CDLL(hip_path.value.decode())
+    N, A, K, reps = env.num_envs, env.num_agents, 8, 250
+
+    def ck(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with HIP error {rc}")
+    stream, graph, gexec, ev0, ev1 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    d_act = env.alloc((N, A), np.int32)
+    d_act.from_host(np.random.default_rng(7).integers(0, env.n_actions, size=(N, A), dtype=np.int32))
+    ck(hip.hipStreamCreateWithFlags(C.byref(stream), 1), "hipStreamCreateWithFlags")
+    try:
+        env.observe_device(d_obs)
+        env.sync()
+        env.set_stream(stream)
+        ck(hip.hipStreamBeginCapture(stream, 0), "hipStreamBeginCapture")            # global mode: the strictest
+        for _ in range(K):
+            _native.check(h, L.cz_probe_policy(h, d_obs.ptr, None, d_act.ptr))
+            env.step_device(d_act, d_obs, d_rew, d_term, d_trunc)
+        ck(hip.hipStreamEndCapture(stream, C.byref(graph)), "hipStreamEndCapture")
+        ck(hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0)), "hipGraphInstantiate")
+        for _ in range(5):
+            ck(hip.hipGraphLaunch(gexec, stream), "hipGraphLaunch")
+        hip.hipEventCreate(C.byref(ev0)); hip.hipEventCreate(C.byref(ev1))
+        s0 = env.stats()["env_steps"]
+        hip.hipEventRecord(ev0, stream)
+        for _ in range(reps):
+            ck(hip.hipGraphLaunch(gexec, stream), "hipGraphLaunch")
+        hip.hipEventRecord(ev1, stream)
+        ck(hip.hipEventSynchronize(ev1), "hipEventSynchronize")
+        ms = C.c_float()
+        hip.hipEventElapsedTime(C.byref(ms), ev0, ev1)
+        us = ms.value * 1e3 / (K * reps)
+        stepped = (env.stats()["env_steps"] - s0) / float(N * K * reps)
+        return {"env_steps_per_s": stepped * N / (us * 1e-6), "us_per_step": us, "envs": N,
+                "what": f"[cz_probe_policy -> cz_step_device] x {K} captured by hipStreamBeginCapture (global mode) on the caller's stream "
+                        f"(cz_set_stream), the caller's graph replayed {reps} times, HIP events on that stream; the gap between two graph launches "
+                        f"(about a microsecond per step at {K} steps per graph) is part of the figure"}
+    finally:
+        env.set_stream(None)
+        for o, f in ((gexec, hip.hipGraphExecDestroy), (graph, hip.hipGraphDestroy), (ev0, hip.hipEventDestroy), (ev1, hip.hipEventDestroy),
+                     (stream, hip.hipStreamDestroy)):
+            if o.value:
+                f(o)
+        d_act.free()
+
+
 def leg_fused_actions(env, K):
     """T = 32 fused steps per launch over actions of the CALLER (cz_rollout_actions: replay / open-loop search), float64
     trajectory [T][N][A][F]"""
@@ -821,6 +876,7 @@ def worker_body(args, rdzv):
             line["ring_fused"] = guarded(leg_ring_fused, env, K, d_obs, d_rew, d_term, d_trunc)
             line["closed_loop"] = guarded(leg_closed_loop, env, d_obs, d_rew, d_term, d_trunc)
             line["closed_loop_compact"] = guarded(leg_closed_loop_compact, env, d_rew, d_term, d_trunc)
+            line["closed_loop_caller_graph"] = guarded(leg_closed_loop_captured, env, d_obs, d_rew, d_term, d_trunc)
             line["cooking_policy"] = guarded(leg_cooking_policy, local_rank)
             line["configs"] = guarded(leg_configs, local_rank)
         if world == 1 and not args.no_cpu_baseline:
