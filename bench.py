@@ -750,8 +750,7 @@ def worker_body(args, rdzv):
     env.step_device_ring(n_ev, d_actions, env.num_envs * 2, period, 0, None if args.no_obs else d_obs, d_rew, d_term, d_trunc)
     _native.check(h, L.cz_timer_stop(h, C.byref(ev_ms)))       # event after the last launch, synchronised
     kernel_us = ev_ms.value * 1e3 / n_ev
-    mine = {"elapsed_s": elapsed, "env_steps": steps_done, "kernel_us": [kernel_us], "stats": env.stats()}
-    every = [json.loads(b) for b in rdzv.all_gather(json.dumps(mine).encode())]
+    mine = {"elapsed_s": elapsed, "env_steps": steps_done, "kernel_us": [kernel_us]}
 
     # ---- a sustained stretch of the headline's launches (a sampler of GPU activity sees the device busy)
     sustained = None
@@ -790,7 +789,13 @@ def worker_body(args, rdzv):
         senv4.close()
 
     # ---- episode statistics: RCCL all-gather over xGMI of one cz_stats per shard (the path's only collective), checked
-    # against the same structs exchanged over the control plane
+    # against the same structs exchanged over the control plane.  The control-plane copy is taken HERE, after every leg that
+    # steps this batch (the sustained stretch above included) and with nothing stepping between it and the RCCL gather -
+    # a copy taken earlier describes an older batch and can never compare equal (BENCH_r05 left with rc 3).
+    senv.sync()
+    senv.barrier()
+    mine["stats"] = env.stats()
+    every = [json.loads(b) for b in rdzv.all_gather(json.dumps(mine).encode())]
     stats_all = {}
     rc = 0
     if comm_ok:
