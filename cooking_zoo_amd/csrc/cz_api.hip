@@ -135,6 +135,22 @@ __global__ void k_layout_misfits(const uint32_t *__restrict__ state, int RW, int
     if (rec[W_LAYOUT] >= n_new || (cnt && base + cnt > n_new)) atomicAdd(count, 1ull);
 }
 
+// cz_set_spawn across the 31-step boundary: the countdown fields of the status word change their width (spawn_grace_bits); the
+// resident records are re-packed so that no env reads another agent's bits (a countdown that does not fit the narrower field is
+// clamped to its maximum, 31 - the new period is at most 31 then, so the agent is protected for at most one period)
+__global__ void k_repack_grace(uint32_t *state, int RW, int N, int n_agents, uint32_t old_bits, uint32_t new_bits) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    uint32_t *rec = state + (size_t)e * RW;
+    const uint32_t st = rec[W_STATUS];
+    uint32_t out = st & ((1u << SPAWN_GRACE0) - 1u);
+    for (int a = 0; a < n_agents; ++a) {
+        const uint32_t g = (st >> (SPAWN_GRACE0 + old_bits * a)) & ((1u << old_bits) - 1u);
+        out |= min(g, (1u << new_bits) - 1u) << (SPAWN_GRACE0 + new_bits * a);
+    }
+    rec[W_STATUS] = out;
+}
+
 __global__ void k_count_aborted(uint32_t *su, const uint32_t *__restrict__ state, int RW, long long env_begin, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -167,6 +183,7 @@ struct cz_handle_s {
     int64_t n_layout_updates = 0;
     void *d_spawn_tables = nullptr;        // cz_set_spawn: exhausted-respawn counter | spawn areas per (level, agent) | level of every layout
     int spawn_layouts = 0;                 // the pool size those tables were made for
+    uint32_t spawn_bits = 5;               // width of the countdown fields the resident records are packed with (spawn_grace_bits)
     uint32_t *d_stat_u = nullptr;
     double *d_stat_f = nullptr;
     cz_stats *d_stats_out = nullptr;
@@ -216,7 +233,7 @@ struct cz_handle_s {
     int64_t tl_count = 0;
     bool graphs_enabled = true;    // CZ_GRAPHS=0: cz_step_device_ring launches everything directly
     bool ring_fused = false;       // cz_set_ring_fused: runs of cz_step_device_ring / _many go out as fused launches (outputs in place)
-    int64_t n_ring_fused_steps = 0, n_ring_fused_launches = 0;
+    int64_t n_ring_fused_steps = 0;
     int32_t graph_min_run = 48;    // CZ_GRAPH_MIN_RUN: shorter pieces of a ring run are launched directly (see ring_walk)
     int32_t ring_prefix = 0;       // CZ_RING_PREFIX: steps of a cz_step_device_ring call launched directly in front of its first graph
     size_t zero_copy_bytes = (size_t)256 << 10;   // cz_step: batches whose buffers fit use the pinned device-mapped block (CZ_ZERO_COPY_BYTES)
@@ -257,6 +274,8 @@ static bool caller_capturing(cz_handle h) {
     if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
     return cs != hipStreamCaptureStatusNone;
 }
+
+extern "C" int32_t cz_stream_capturing(cz_handle h) { return h && caller_capturing(h) ? 1 : 0; }
 
 extern "C" int32_t cz_abi_version(void) { return CZ_ABI_VERSION; }
 // diagnostic builds only (tools/phase_profile.py): where the kernels write their s_memtime stamps
@@ -353,7 +372,7 @@ extern "C" int cz_create(const cz_config *cfg, cz_handle *out) {
     P.T = 1;
     if (const char *s = getenv("CZ_WT")) h->wt_override = atoi(s);
     if (const char *s = getenv("CZ_GRAPHS")) h->graphs_enabled = atoi(s) != 0;
-    if (const char *s = getenv("CZ_GRAPH_MIN_RUN")) h->graph_min_run = atoi(s) < 4 ? 4 : atoi(s);
+    if (const char *s = getenv("CZ_GRAPH_MIN_RUN")) h->graph_min_run = atoi(s) < 4 ? 4 : (atoi(s) > 256 ? 256 : atoi(s));   // 4..RING_MAX_GRAPH
     if (const char *s = getenv("CZ_RING_PREFIX")) h->ring_prefix = atoi(s) < 0 ? 0 : (atoi(s) > 16 ? 16 : atoi(s));
     if (const char *s = getenv("CZ_ZERO_COPY_BYTES")) h->zero_copy_bytes = (size_t)atoll(s);
 #ifdef CZ_SMALL_ONLY       // diagnostic libraries that carry the small instance only
@@ -525,6 +544,14 @@ extern "C" int cz_set_spawn(cz_handle h, double despawn_rate, double respawn_rat
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->d_spawn_tables) { HIPCHK(h, hipFree(h->d_spawn_tables)); h->d_spawn_tables = nullptr; }
     h->spawn_layouts = 0;
+    const uint32_t new_bits = spawn_grace_bits((uint32_t)grace_period, h->P.A);
+    if (new_bits != h->spawn_bits) {       // episodes in flight keep their countdowns: re-pack them to the new field width
+        hipLaunchKernelGGL(k_repack_grace, dim3((unsigned)((h->P.N + 255) / 256)), dim3(256), 0, h->stream, h->d_state, h->P.RW, (int)h->P.N,
+                           h->P.A, h->spawn_bits, new_bits);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->spawn_bits = new_bits;
+    }
     if (on) {
         // one allocation: the counter word, the areas, the level of every layout
         const size_t off_areas = 16, off_levels = off_areas + ((areas.size() + 15) & ~(size_t)15);
@@ -1060,10 +1087,11 @@ extern "C" int cz_step_device_many(cz_handle h, int32_t K, const int32_t *d_acti
 // step k reads slot (first_slot + k) % period.  A run of consecutive slots is captured once into a HIP graph, keyed by
 // (first slot, length), and replayed afterwards: that takes the host out of the loop (0.02 us instead of ~2.5 us of CPU
 // per launch) and the kernels read their arguments from memory that is not rewritten before every launch.  A run is cut
-// where the ring wraps and at RING_MAX_GRAPH launches; pieces shorter than RING_MIN_GRAPH are launched directly.  At
+// where the ring wraps and at RING_MAX_GRAPH launches; pieces shorter than the handle's graph_min_run (48; CZ_GRAPH_MIN_RUN, clamped to
+// 4..RING_MAX_GRAPH) are launched directly.  At
 // most RING_CACHE graphs are kept (least recently used goes first), so a caller that keeps asking for new (slot, length)
 // pairs pays a capture each time -- keep the runs of a loop aligned.  Results are identical to cz_step_device_many.
-constexpr int RING_MIN_GRAPH = 4, RING_MAX_GRAPH = 256, RING_CACHE = 64;   // (rocprofv3 --kernel-trace aborts on replays of ~1000 kernel nodes: malformed AQL packet)
+constexpr int RING_MAX_GRAPH = 256, RING_CACHE = 64;   // (rocprofv3 --kernel-trace aborts on replays of ~1000 kernel nodes: malformed AQL packet)
 // captures the launches of slots [slot, slot + len) (nothing executes) and instantiates them
 static int ring_capture(cz_handle h, Params &P, const int32_t *d_ring, int64_t stride, int32_t slot, int32_t len, hipGraphExec_t &ge) {
     hipGraph_t g = nullptr;
@@ -1135,7 +1163,6 @@ static int launch_ring_fused(cz_handle h, Params &P, int32_t K, const int32_t *d
         Q.T = (int32_t)run; Q.seed = 0; Q.step0 = 1u;          // bit 0: outputs in place
         if (launch_step(h, Q, nullptr, true)) return 1;
         k += (int32_t)run;
-        h->n_ring_fused_launches++;
     }
     h->n_ring_fused_steps += K;
     return 0;
@@ -1158,11 +1185,11 @@ static int ring_walk(cz_handle h, int32_t K, const int32_t *d_ring, int64_t stri
         // Short pieces go out as plain launches: a graph's first kernel starts ~10-16 us after hipGraphLaunch, a directly launched one
         // after ~3-5 us, and the host enqueues a launch (2.8 us) faster than the device runs it - a 20-step region takes 6.7 us per step
         // launched directly against 6.85 us replayed (profiles/r05/k20_modes.txt); long runs are replayed (no host work per launch).
-        if (graphs && run >= h->graph_min_run + h->ring_prefix) {
-            // Replaying a graph costs the host ~10-16 us before its first kernel starts; a directly launched kernel starts
-            // after ~3-5 us.  So the first `ring_prefix` steps of a piece go out as plain launches and keep the GPU busy
-            // while the host submits the graph of the rest behind them.
-            const int32_t pre = k == 0 ? h->ring_prefix : 0;
+        // Replaying a graph costs the host ~10-16 us before its first kernel starts; a directly launched kernel starts
+        // after ~3-5 us.  So the first `ring_prefix` steps of a call's first piece go out as plain launches and keep the GPU busy
+        // while the host submits the graph of the rest behind them.
+        const int32_t pre = k == 0 ? h->ring_prefix : 0;
+        if (graphs && run >= h->graph_min_run + pre) {
             hipGraphExec_t ge = nullptr;
             if (ring_graph(h, P, d_ring, stride, slot + pre, run - pre, ge)) return 1;
             if (launch) {

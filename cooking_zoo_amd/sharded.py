@@ -373,6 +373,10 @@ class ShardedVecEnv:
     def stop_rotation(self):
         self._each(lambda i, env: env.stop_rotation())
 
+    def advance(self, k):
+        """`CookingVecEnv.advance` on every shard: k env steps ran as replays of a graph of the caller that holds captured launches"""
+        self._each(lambda i, env: env.advance(k))
+
     @property
     def rotation_events(self):
         return self.shards[0].rotation_events

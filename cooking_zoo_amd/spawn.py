@@ -141,8 +141,9 @@ def max_grace(num_agents):
     return (1 << b) - 1 if b > 5 else 31
 
 
-def status_bits(active, grace, bits=5):
-    """[N, A] bool active, [N, A] int grace -> uint32 [N] to be or-ed into the status word (`bits`: grace_bits(grace_period, A))"""
+def status_bits(active, grace, bits):
+    """[N, A] bool active, [N, A] int grace -> uint32 [N] to be or-ed into the status word.  `bits` = grace_bits(grace_period, A) of the
+    batch the words are for - required: a record does not say which width it was packed with"""
     out = np.zeros(active.shape[0], dtype=np.uint32)
     for a in range(active.shape[1]):
         out |= (~active[:, a]).astype(np.uint32) << np.uint32(SPAWN_GONE0 + a)
@@ -150,8 +151,8 @@ def status_bits(active, grace, bits=5):
     return out
 
 
-def decode_status(status, num_agents, bits=5):
-    """uint32 [N] status words -> (active [N, A] bool, grace [N, A] int64)"""
+def decode_status(status, num_agents, bits):
+    """uint32 [N] status words -> (active [N, A] bool, grace [N, A] int64); `bits` = grace_bits(grace_period, A) of the batch they come from"""
     status = np.asarray(status, dtype=np.uint32)
     active = np.empty((status.shape[0], num_agents), dtype=bool)
     grace = np.empty((status.shape[0], num_agents), dtype=np.int64)

@@ -265,7 +265,9 @@ class CookingVecEnv:
         _native.check(self._h, L.cz_load_recipes(self._h, _ptr(self.recipe_table), len(self.book_names), self.recipe_nodes))
         self._upload_layouts()
         self._buffers = []
-        self._steps = 0                       # env steps issued so far (every stepping method counts)
+        self._steps = 0                       # env steps issued so far (every stepping method counts; `advance` adds replayed ones)
+        self.captured_steps = 0               # steps captured into graphs of the caller (they run at replay, see `advance`)
+        self._caller_stream, self._warned_capture = False, False
         self._lay_groups, self._lay_active = 1, 0
         self._rot = None                      # rotate_layouts state
         self.rotation_events = []             # (step index, "group", groups, active) / (step index, "layouts", first slot, [Layout])
@@ -292,6 +294,15 @@ class CookingVecEnv:
                 sy[li, a, :len(ys)] = [v if 0 <= v < 255 else 255 for v in ys]
         d, r, g, seed = self._spawn_cfg
         _native.check(self._h, L.cz_set_spawn(self._h, d, r, g, seed, nl, _ptr(self.level_of_layout), stride, _ptr(sx), _ptr(nx), _ptr(sy), _ptr(ny)))
+
+    def set_spawn_rates(self, agent_despawn_rate, agent_respawn_rate, grace_period, spawn_seed=None):
+        """Change the despawn / respawn parameters of a live batch (cz_set_spawn: takes effect with the next step; running episodes keep
+        their countdowns, re-packed by the library if the period crosses 31 and the fields change their width)."""
+        if self.spawn_cells is None:
+            raise ValueError("the env was made without despawn / respawn (no spawn areas were collected)")
+        seed = self._spawn_cfg[3] if spawn_seed is None else int(spawn_seed)
+        self._spawn_cfg = (float(agent_despawn_rate), float(agent_respawn_rate), int(grace_period), seed)
+        self._set_spawn()
 
     def spawn_exhausted(self):
         """respawns that found no free cell of their spawn area in 1001 tries (the reference raises there) since the env was made"""
@@ -349,7 +360,9 @@ class CookingVecEnv:
         layouts an env sees is a function of the sequence of stepping calls only (the refill waits for that process if it
         has to), so a run can be replayed: `rotation_events` lists what was switched / replaced at which step.
         `blocking=False` never waits: a refill whose layouts are not ready yet is tried again at the next call boundary (and
-        the next switch with it), which keeps the stepping thread free of stalls at the price of a timing-dependent schedule."""
+        the next switch with it), which keeps the stepping thread free of stalls at the price of a timing-dependent schedule.
+        Steps that run as replays of a graph of the CALLER (captured `step_device*` launches) are invisible here: report them with
+        `advance(k)` after every replay - the switches and refills then happen in that call, between replays."""
         if self._rot is not None:
             raise RuntimeError("rotate_layouts is already running")
         if groups < 2 or any(count % groups for _, count in self.pool_slices):
@@ -419,6 +432,28 @@ class CookingVecEnv:
     def rotation_ready(self):
         """refills the background process has ready right now (a measurement may want to start with a full queue)"""
         return 0 if self._rot is None else self._rot["ready"].qsize()
+
+    def _issued(self, k):
+        """a device-pointer call of k steps has returned: count them - unless the call was CAPTURED into a graph of the caller
+        (nothing ran; the steps run whenever that graph is replayed, which Python does not see: the caller reports them with
+        `advance`)"""
+        if self._caller_stream and _native.lib().cz_stream_capturing(self._h):
+            self.captured_steps += int(k)
+            if self._rot is not None and not self._warned_capture:
+                self._warned_capture = True
+                import warnings
+                warnings.warn("steps captured into a graph of the caller while rotate_layouts is active: call env.advance(k) after "
+                              "every replay of k captured steps, or the layout pool is never switched / refilled", RuntimeWarning, stacklevel=3)
+            return
+        self._advance(k)
+
+    def advance(self, k):
+        """Tell the env that k env steps ran which it did not issue itself: replays of a graph of the caller that holds captured
+        `step_device*` / `rollout*` launches (hipGraphLaunch, torch.cuda.CUDAGraph.replay()).  Keeps `rotate_layouts` on schedule:
+        the switch to the next part of the pool and the refill of the retired one happen here, between replays."""
+        if self._caller_stream and _native.lib().cz_stream_capturing(self._h):
+            raise RuntimeError("advance() inside a stream capture: call it after the replay, outside the capture")
+        self._advance(k)
 
     def _advance(self, k):
         """k more env steps have been issued: switch / refill when due"""
@@ -597,6 +632,7 @@ class CookingVecEnv:
         raw = getattr(stream, "cuda_stream", stream)
         raw = getattr(raw, "value", raw)                               # (ctypes.c_void_p)
         _native.check(self._h, _native.lib().cz_set_stream(self._h, C.c_void_p(int(raw)) if raw else None))
+        self._caller_stream = bool(raw)
 
     def step_device(self, d_actions, d_obs, d_rewards, d_term, d_trunc):
         """Device-resident step.  Buffers: DeviceBuffer, a raw device address (int), or anything with `data_ptr()`
@@ -605,7 +641,7 @@ class CookingVecEnv:
         p = _dev_ptr
         _native.check(self._h, _native.lib().cz_step_device(self._h, p(d_actions), p(d_obs), p(d_rewards), p(d_term),
                                                             p(d_trunc)))
-        self._advance(1)
+        self._issued(1)
 
     def step_device_compact(self, d_actions, d_codes, d_rewards, d_term, d_trunc, d_obs=None):
         """Device-resident step whose observation is one byte per feature: d_codes uint8 [N, A, codes_pitch] receives the index
@@ -614,7 +650,7 @@ class CookingVecEnv:
         p = _dev_ptr
         _native.check(self._h, _native.lib().cz_step_device_compact(self._h, p(d_actions), p(d_codes), p(d_obs), p(d_rewards), p(d_term),
                                                                     p(d_trunc)))
-        self._advance(1)
+        self._issued(1)
 
     def set_compact_output(self, d_codes=None):
         """every one-step launch from now on (step_device, step_device_ring, step) also writes the compact observation to d_codes
@@ -638,20 +674,20 @@ class CookingVecEnv:
         p = _dev_ptr
         _native.check(self._h, _native.lib().cz_step_device_ring(self._h, int(K), p(d_ring), int(action_stride), int(action_period),
                                                                  int(first_slot), p(d_obs), p(d_rewards), p(d_term), p(d_trunc)))
-        self._advance(K)
+        self._issued(K)
 
     def rollout(self, T, seed, step0=0, d_obs=None, d_rewards=None, d_term=None, d_trunc=None):
         p = _dev_ptr
         _native.check(self._h, _native.lib().cz_rollout(self._h, int(T), int(seed), int(step0), p(d_obs), p(d_rewards),
                                                         p(d_term), p(d_trunc)))
-        self._advance(T)
+        self._issued(T)
 
     def rollout_compact(self, T, seed, step0, d_codes, d_obs=None, d_rewards=None, d_term=None, d_trunc=None):
         """`rollout` with a compact trajectory: d_codes uint8 [T, N, A, codes_pitch] (and, optionally, the float64 one)"""
         p = _dev_ptr
         _native.check(self._h, _native.lib().cz_rollout_compact(self._h, int(T), int(seed), int(step0), p(d_codes), p(d_obs), p(d_rewards),
                                                                 p(d_term), p(d_trunc)))
-        self._advance(T)
+        self._issued(T)
 
     def rollout_actions(self, d_actions, T, d_obs=None, d_rewards=None, d_term=None, d_trunc=None):
         """T fused steps over the caller's actions (device int32 [T, N, A]); every step's outputs go to the trajectory
@@ -659,7 +695,7 @@ class CookingVecEnv:
         p = _dev_ptr
         _native.check(self._h, _native.lib().cz_rollout_actions(self._h, int(T), p(d_actions), p(d_obs), p(d_rewards),
                                                                 p(d_term), p(d_trunc)))
-        self._advance(T)
+        self._issued(T)
 
     def sync(self):
         _native.check(self._h, _native.lib().cz_sync(self._h))

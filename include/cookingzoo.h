@@ -42,7 +42,7 @@ extern "C" {
 
 /* The one place the ABI number lives: cz_abi_version() returns it, cooking_zoo_amd/_native.py parses it from this file
  * and refuses a library that reports another one, __graft_entry__.build() and the tests compare against it. */
-#define CZ_ABI_VERSION 7
+#define CZ_ABI_VERSION 8
 
 typedef struct cz_handle_s *cz_handle;
 
@@ -103,7 +103,11 @@ int cz_set_stream(cz_handle h, void *hip_stream);
  * of the caller's graph then do exactly what the captured launches did (cooking_env.py:243-288 once per captured step).  Calls
  * that copy to / from the host or wait (cz_step, cz_reset, cz_get_state, cz_sync, cz_get_stats, cz_update_layouts,
  * cz_set_layout_group ...) are not; the last two say so, the others fail with HIP's own error.  The captured launches carry the
- * table pointers of their time: after cz_load_layouts / cz_load_recipes / cz_set_spawn / cz_set_compact_output capture again. */
+ * table pointers of their time: after cz_load_layouts / cz_load_recipes / cz_set_spawn / cz_set_compact_output capture again.
+ * cz_stream_capturing: 1 while the handle's stream is a stream of the caller that is being captured, else 0 - a host layer that
+ * keeps count of the steps it issued (cooking_zoo_amd: layout rotation schedules) must not count captured launches as steps:
+ * they run when the caller's graph is replayed, as often as it is replayed. */
+int32_t cz_stream_capturing(cz_handle h);
 
 /* ---- tables ---------------------------------------------------------------------------------------- */
 /* Recipe graphs: replaces RECIPES[name]() / Recipe.node_list (recipe_drawer.py:109-118, recipe.py:29-34).
@@ -152,7 +156,11 @@ int64_t cz_layout_updates(cz_handle h);
  * says), is reported truncated in the step it leaves, and stays in the world as an obstacle; an agent that holds something stays.
  * TAKES EFFECT WITH THE NEXT STEP: worlds reset from then on start with everybody present and the grace period running
  * (parsing.py:142); episodes that are already running continue with whatever their status words hold (grace 0 unless the
- * caller set it), i.e. they draw from their next step on.  Rates 0, 0 switch it off.
+ * caller set it), i.e. they draw from their next step on.  A call that moves grace_period across 31 changes the width of the
+ * countdown fields: the resident records are re-packed to the new width by the call itself (a countdown that does not fit the
+ * narrower field becomes 31).  A record does not say which width it was packed with: cz_set_state takes records in the width
+ * of the handle's CURRENT grace_period (records saved under the other width must be re-packed by the caller,
+ * cooking_zoo_amd/spawn.py decode_status / status_bits).  Rates 0, 0 switch it off.
  * Spawn areas (the level files' AGENTS entries, parsing.py:118-151) are per level: level_of_layout[i] (NULL: all 0) is the
  * level that layout i of the resident pool instantiates - call again after cz_load_layouts changed the pool size -,
  * spawn_x / spawn_y are [n_levels][num_agents][stride] candidate coordinates, n_x / n_y [n_levels][num_agents] how many of

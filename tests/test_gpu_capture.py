@@ -150,3 +150,51 @@ def test_ring_runs_and_rollouts_inside_a_capture():
     env.set_stream(None)
     hip.lib.hipStreamDestroy(stream)
     env.close(); ref.close()
+
+
+def test_rotating_pool_under_replays_of_a_callers_graph():
+    """rotate_layouts + a captured step loop: capturing a launch is not a step - the env's step count (and with it the
+    switch / refill schedule) does not move at capture time; the caller reports every replay with `advance(K)`, and the pool then
+    rotates exactly as under eager launches of the same steps: same events at the same step numbers, same final records."""
+    import warnings
+    hip = Hip()
+    n, A, K, R = 256, 2, 10, 60
+    env, ref = make(n, num_layouts=16, layout_seed=11), make(n, num_layouts=16, layout_seed=11)
+    be, br = buffers(env), buffers(ref)
+    ring = np.random.default_rng(5).integers(0, 5, size=(K, n, A), dtype=np.int32)
+    de, dr = env.alloc((K, n, A), np.int32), ref.alloc((K, n, A), np.int32)
+    de.from_host(ring); dr.from_host(ring)
+    env.reset(return_obs=False); ref.reset(return_obs=False)
+    stream = C.c_void_p()
+    hip.ck(hip.lib.hipStreamCreateWithFlags(C.byref(stream), 1), "hipStreamCreateWithFlags")
+    env.set_stream(stream)
+    for e in (env, ref):
+        e.rotate_layouts(50, groups=2, seed=3, prefetch=2)
+    graph, gexec = C.c_void_p(), C.c_void_p()
+    hip.ck(hip.lib.hipStreamBeginCapture(stream, 0), "hipStreamBeginCapture")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        env.step_device_ring(K, de, n * A, K, 0, be["obs"], be["rew"], be["term"], be["trunc"])
+        with pytest.raises(RuntimeError, match="inside a stream capture"):
+            env.advance(K)
+    assert any("advance(k)" in str(x.message) for x in w)
+    hip.ck(hip.lib.hipStreamEndCapture(stream, C.byref(graph)), "hipStreamEndCapture")
+    hip.ck(hip.lib.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0)), "hipGraphInstantiate")
+    assert env._steps == 0 and env.captured_steps == K and env.rotation_events == []
+    for _ in range(R):
+        hip.ck(hip.lib.hipGraphLaunch(gexec, stream), "hipGraphLaunch")
+        env.advance(K)
+        ref.step_device_ring(K, dr, n * A, K, 0, br["obs"], br["rew"], br["term"], br["trunc"])
+    hip.ck(hip.lib.hipStreamSynchronize(stream), "hipStreamSynchronize")
+    ref.sync()
+    assert env._steps == ref._steps == K * R
+    sig = lambda evs: [(e[0], e[1], e[2], e[3] if e[1] == "group" else [l.key() for l in e[3]]) for e in evs]
+    assert sig(env.rotation_events) == sig(ref.rotation_events)
+    assert sum(e[1] == "group" for e in env.rotation_events) >= 10 and sum(e[1] == "layouts" for e in env.rotation_events) >= 8
+    assert np.array_equal(env.get_state(), ref.get_state())
+    assert np.array_equal(bits(be["obs"].to_host()), bits(br["obs"].to_host()))
+    hip.lib.hipGraphExecDestroy(gexec); hip.lib.hipGraphDestroy(graph)
+    env.stop_rotation(); ref.stop_rotation()
+    env.set_stream(None)
+    hip.lib.hipStreamDestroy(stream)
+    env.close(); ref.close()

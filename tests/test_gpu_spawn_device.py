@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from cooking_zoo_amd import soa
-from cooking_zoo_amd.spawn import SpawnBook, status_bits
+from cooking_zoo_amd.spawn import SpawnBook, grace_bits, status_bits
 
 pytestmark = pytest.mark.gpu
 KW = dict(action_scheme="scheme3", num_layouts=6, auto_reset=True, agent_despawn_rate=0.15, agent_respawn_rate=0.25, grace_period=2, spawn_seed=5)
@@ -44,7 +44,7 @@ class Model:
 
     def records(self):
         r = self.orc.records.copy()
-        r[:, soa.W_STATUS] |= status_bits(self.book.active, self.book.grace)
+        r[:, soa.W_STATUS] |= status_bits(self.book.active, self.book.grace, grace_bits(self.book.grace_period, self.book.A))
         return r
 
     def step(self, acts):
@@ -265,6 +265,48 @@ def test_grace_periods_beyond_31(agents, grace, level, meta, recipes):
         # somebody has left and come back by now: its countdown was restarted, a value beyond what five bits hold lives in the record
         _, g = decode_status(orc.records[:, soa.W_STATUS], agents, b)
         assert (g > 31).any() and (g <= grace).all()
+    env.close()
+
+
+def test_grace_width_change_repacks_running_episodes():
+    """cz_set_spawn across the 31 boundary while episodes run: the countdown fields change their width and the library
+    re-packs the resident records - every agent keeps its countdown (agent a > 0's field moves), going back narrows with a clamp to 31 -
+    and the batch then steps exactly like an oracle whose records were re-packed the same way."""
+    from cooking_zoo_amd.spawn import decode_status, grace_bits, status_bits
+    from cooking_zoo_amd.vec_env import CookingVecEnv
+    from oracle_binding import VecOracle
+    n, A = 96, 2
+    kw = dict(action_scheme="scheme3", num_layouts=4, agent_despawn_rate=0.3, agent_respawn_rate=0.5, grace_period=20, spawn_seed=9)
+    env = CookingVecEnv(n, "coop_test", "example", A, 400, ["TomatoLettuceSalad", "CarrotBanana"], **kw)
+    env.reset(return_obs=False)
+    env.rollout(30, 4, 100); env.sync()
+    st5 = env.get_state()
+    act5, g5 = decode_status(st5[:, soa.W_STATUS], A, 5)
+    assert (g5 > 0).any() and (~act5).any()
+    env.set_spawn_rates(0.3, 0.5, 200)                                  # 5 -> 10 bits per countdown
+    st10 = env.get_state()
+    act10, g10 = decode_status(st10[:, soa.W_STATUS], A, grace_bits(200, A))
+    assert np.array_equal(act10, act5) and np.array_equal(g10, g5)
+    other = np.ones(st5.shape[1], dtype=bool); other[soa.W_STATUS] = False
+    assert np.array_equal(st10[:, other], st5[:, other]) and np.array_equal(st10[:, soa.W_STATUS] & 0xFFF, st5[:, soa.W_STATUS] & 0xFFF)
+    assert np.array_equal(env.spawn.grace, g5)
+    # from here on: an oracle of the new configuration, started from the re-packed records
+    orc = VecOracle.from_vec_env(env)
+    orc.reset()
+    orc.records[:] = strip(st10)
+    rng = np.random.default_rng(4)
+    for t in range(60):
+        acts = rng.integers(0, 5, size=(n, A), dtype=np.int32)
+        og, rg, tg, ug = env.step(acts)
+        oo, ro, to, uo = orc.step(acts)
+        assert np.array_equal(bits(og), bits(oo)) and np.array_equal(tg, to) and np.array_equal(ug, uo), t
+        assert np.array_equal(strip(env.get_state()), orc.records), t
+    _, g = decode_status(env.get_state()[:, soa.W_STATUS], A, 10)
+    assert (g > 31).any()                                              # somebody came back under the long period
+    env.set_spawn_rates(0.3, 0.5, 8)                                    # 10 -> 5 bits: clamp to 31
+    act_b, g_b = decode_status(env.get_state()[:, soa.W_STATUS], A, 5)
+    act_a, _ = decode_status(orc.records[:, soa.W_STATUS], A, 10)
+    assert np.array_equal(act_b, act_a) and np.array_equal(g_b, np.minimum(g, 31))
     env.close()
 
 

@@ -204,3 +204,26 @@ def test_stale_library_is_refused(repo_root, tmp_path):
             "try:\n    _native.lib()\nexcept _native.NativeError as e:\n    print('REFUSED', e); sys.exit(0)\nsys.exit(3)") % (str(so), repo_root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.returncode == 0 and "REFUSED" in out.stdout and "ABI 1" in out.stdout, out.stdout + out.stderr
+
+
+def test_package_without_the_repo_header_still_knows_its_abi(repo_root, tmp_path):
+    """cooking_zoo_amd/ copied somewhere without include/ (a wheel, a vendored copy): the expected ABI number comes from the generated
+    cooking_zoo_amd/_abi.py, which equals the header's; without either the failure is a NativeError that says what is missing
+    (it used to be a FileNotFoundError at the first env creation)."""
+    import shutil
+    import subprocess
+    import sys
+    from cooking_zoo_amd import _abi, _native
+    assert _abi.CZ_ABI_VERSION == _native.header_abi_version()
+    shutil.copytree(os.path.join(repo_root, "cooking_zoo_amd"), tmp_path / "site" / "cooking_zoo_amd",
+                    ignore=shutil.ignore_patterns("__pycache__", "*.o", "*_prof.so", "*_mark.so", "*_tl.so", "cuts", "*.s"))
+    code = ("import sys; sys.path.insert(0, %r)\nfrom cooking_zoo_amd import _native\n"
+            "assert not __import__('os').path.exists(_native.HEADER_PATH)\n"
+            "L = _native.lib(); print('ABI', L.cz_abi_version(), _native.header_abi_version())") % str(tmp_path / "site")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0 and f"ABI {_abi.CZ_ABI_VERSION} {_abi.CZ_ABI_VERSION}" in out.stdout, out.stdout + out.stderr
+    os.remove(tmp_path / "site" / "cooking_zoo_amd" / "_abi.py")
+    code2 = ("import sys; sys.path.insert(0, %r)\nfrom cooking_zoo_amd import _native\n"
+             "try:\n    _native.lib()\nexcept _native.NativeError as e:\n    print('REFUSED', e); sys.exit(0)\nsys.exit(3)") % str(tmp_path / "site")
+    out = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0 and "REFUSED" in out.stdout and "_abi.py" in out.stdout, out.stdout + out.stderr

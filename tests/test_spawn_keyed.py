@@ -60,8 +60,8 @@ def test_oracle_replays_keyed_despawn_respawn(name):
             assert np.array_equal(bits(obs), bits(ep.obs[t + 1])), f"{ctx}: observation"
             assert np.array_equal(bits(rew), bits(ep.rewards[t])), f"{ctx}: reward {rew} vs {ep.rewards[t]}"
             assert np.array_equal(term, ep.terms[t]) and np.array_equal(trunc, ep.truncs[t]), f"{ctx}: flags"
-            a0, _ = spawn.decode_status(before[soa.W_STATUS:soa.W_STATUS + 1], ep.dims.A)
-            a1, _ = spawn.decode_status(rec[soa.W_STATUS:soa.W_STATUS + 1], ep.dims.A)
+            a0, _ = spawn.decode_status(before[soa.W_STATUS:soa.W_STATUS + 1], ep.dims.A, 5)     # (fixtures: grace periods <= 31)
+            a1, _ = spawn.decode_status(rec[soa.W_STATUS:soa.W_STATUS + 1], ep.dims.A, 5)
             n_gone += int((a0 & ~a1).sum())
             n_back += int((~a0 & a1).sum())
             n_moved += sum(int(before[soa.AGENT_WORD0 + a] & 0xFFFF != rec[soa.AGENT_WORD0 + a] & 0xFFFF) for a in range(ep.dims.A) if not a0[0, a] and a1[0, a])

@@ -671,7 +671,8 @@ def capture_spawn_keyed_episode(cfg, seed, policy_name, rates, env_id, episode_n
         rec = world_to_record(env, dims, slotmap, 0, recipe_ids)
         rec[soa.W_EPISODE] = episode_no
         rec[soa.W_STATUS] |= czspawn.status_bits(np.array([world.active_agents], dtype=bool),
-                                                 np.array([world.agent_grace_period], dtype=np.int64))[0]
+                                                 np.array([world.agent_grace_period], dtype=np.int64),
+                                                 czspawn.grace_bits(grace, A))[0]
         return rec
 
     full_obs = lambda: np.stack([env.get_feature_vector(a) for a in env.possible_agents])
