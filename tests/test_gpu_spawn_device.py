@@ -289,7 +289,7 @@ def test_grace_width_change_repacks_running_episodes():
     assert np.array_equal(act10, act5) and np.array_equal(g10, g5)
     other = np.ones(st5.shape[1], dtype=bool); other[soa.W_STATUS] = False
     assert np.array_equal(st10[:, other], st5[:, other]) and np.array_equal(st10[:, soa.W_STATUS] & 0xFFF, st5[:, soa.W_STATUS] & 0xFFF)
-    assert np.array_equal(env.spawn.grace, g5)
+    assert np.array_equal(env.spawn.refresh().grace, g5)               # (the view decodes with the width of the current period)
     # from here on: an oracle of the new configuration, started from the re-packed records
     orc = VecOracle.from_vec_env(env)
     orc.reset()
