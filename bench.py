@@ -21,7 +21,7 @@ gets; this file only times it.
 Timing: W warmup steps, then the K-step region is timed `--repeats` times; every region is bracketed by a stream
 synchronisation + barrier over all ranks on both sides, its time is the MAX over ranks, and `value` / `ms_per_step` are
 the MEDIAN over the regions (min and max are reported next to it).  Every timed launch is the boundary-ordered one-step kernel
-`cz::k_step<1,1,2,3,0>` replayed from HIP graphs: `value`, `roofline.kernel_us` and profiles/r05/kernel_stats.csv describe the same
+`cz::k_step<1,1,2,3,0>` replayed from HIP graphs: `value`, `roofline.kernel_us` and profiles/rNN/kernel_stats.csv (newest round) describe the same
 launches.
 """
 import argparse
@@ -115,6 +115,12 @@ def cpu_baseline(env, seconds_target=15.0):
     return out
 
 
+def latest_profile(name):
+    """repo-relative path of the newest profiles/rNN/<name> that exists (the round's own collection once it has been made)"""
+    found = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", name)))
+    return os.path.relpath(found[-1], REPO) if found else f"profiles/rNN/{name} (not collected)"
+
+
 def pmc_traffic(kernel_key):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/rNN/traffic.json), or None."""
     best = None
@@ -135,7 +141,7 @@ CU_COUNT, SHADER_GHZ = 256, 2.4           # MI355X_MICROARCH.md: 256 CUs (8 XCDs
 
 def issue_counts(instance):
     """Instructions per env-step of one kernel instance (scalar / vector / LDS), from the committed rocprofv3 --pmc passes of this
-    round or the last one that has them (profiles/rNN/issue_per_env_step.json, tools/collect_r05.sh), or None."""
+    round or the last one that has them (profiles/rNN/issue_per_env_step.json, tools/collect_round.sh), or None."""
     best = None
     for d in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "issue_per_env_step.json"))):
         try:
@@ -837,9 +843,9 @@ def worker_body(args, rdzv):
         roof = roofline_block(b_alg, N, kernel_us, "cz::k_step<1,1,2,3,0> (one wavefront per env, 8 envs per workgroup)",
                               f"HIP events on the kernels' stream around {n_ev} launches issued back to back (graph replay, ordered by launch "
                               f"boundaries) - the launches `value` times -, divided by the number of launches; rocprofv3 --kernel-trace of the same "
-                              f"command: profiles/r05/kernel_stats.csv", "k_step<1,1,2,3,0>")
+                              f"command: {latest_profile('kernel_stats.csv')}", "k_step<1,1,2,3,0>")
         roof["traffic"] = pmc_traffic(f"k_step_{N}")
-        roof["traffic_from"] = "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately) of the same kernel: profiles/r05/traffic.json (r04's until collected)"
+        roof["traffic_from"] = f"rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately) of the same kernel: {latest_profile('traffic.json')}"
         # measured on this box, same run: a kernel of the same grid shape that ONLY writes the observation bytes (write-through
         # 16-byte stores); write-only traffic does not reach the 8 TB/s read+write peak
         roof["output_only_launch_us"] = out_only_us

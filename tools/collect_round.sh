@@ -1,8 +1,10 @@
 #!/bin/bash
-# GPU box: what profiles/r05/ holds of rocprofv3, from one box.  usage: bash tools/collect_r05.sh   (results under gpurun_out/r05/)
+# GPU box: what profiles/rNN/ holds of rocprofv3, from one box.  usage: bash tools/collect_round.sh r06   (results under gpurun_out/r06/;
+# issue_per_env_step.json and traffic.json are also put into profiles/r06/ on the box so that the last bench line reads them)
 # Every profiled command is the program itself behind `--` and runs under `timeout`.
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
-O=gpurun_out/r05
+R=${1:?round directory name, e.g. r06}
+O=gpurun_out/$R
 rm -rf $O; mkdir -p $O/trace $O/trace_k20 $O/fetch $O/write
 # 1. the bench line, then the same command under a kernel trace: the headline's launches ARE the roofline's kernel
 timeout 900 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
@@ -41,12 +43,12 @@ if f[0] and w[0]:
     t = (2 * f[0] + w[0]) * 1024
     json.dump({"k_step_4096": t, "FETCH_SIZE_KB": f[0], "WRITE_SIZE_KB": w[0], "algorithmic_bytes": alg, "ratio": t / alg,
                "dispatches_averaged": {"fetch": f[1], "write": w[1]}, "_kernel": "cz::k_step<1,1,2,3,0>, launches ordered by launch boundaries",
-               "_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_r05.sh), bytes per launch = (2 x FETCH_SIZE + "
+               "_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_round.sh), bytes per launch = (2 x FETCH_SIZE + "
                        "WRITE_SIZE) x 1024: FETCH_SIZE counts 128-B requests at 64 B on gfx950 (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact for "
                        "16-B-per-lane stores"}, open(O+"/traffic.json", "w"), indent=1)
 PY
 # 4. the bench line again now that this box's instruction counts exist (issue blocks filled in from this box)
-mkdir -p profiles/r05 && cp $O/issue_per_env_step.json profiles/r05/issue_per_env_step.json && cp $O/traffic.json profiles/r05/traffic.json 2>/dev/null
+mkdir -p profiles/$R && cp $O/issue_per_env_step.json profiles/$R/issue_per_env_step.json && cp $O/traffic.json profiles/$R/traffic.json 2>/dev/null
 timeout 900 python3 bench.py > $O/bench_default_with_issue.json 2> /dev/null
 rm -rf $O/trace $O/trace_k20 $O/fetch $O/write $O/inst_*_a $O/inst_*_b
 ls -la $O; cat $O/kernel_stats.csv | cut -c1-200 | head -8; cat $O/issue_per_env_step.json

@@ -16,7 +16,7 @@ def main():
     root = sys.argv[1]
     out = {"_how": "rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES (one pass) and SQ_INSTS_SMEM SQ_INSTS_BRANCH "
                    "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR (another) over tools/instance_loop.py FORM, 4096 envs of the bench workload; per "
-                   "wave (= per env) and launch, divided by the env steps a launch makes (tools/collect_r05.sh)"}
+                   "wave (= per env) and launch, divided by the env steps a launch makes (tools/collect_round.sh)"}
     for line_file in sorted(glob.glob(os.path.join(root, "inst_*.out"))):
         m = re.search(r"instance=(\S+) steps_per_launch=(\d+)", open(line_file).read())
         if not m:
