@@ -280,6 +280,10 @@ class ShardedVecEnv:
     def spawn_exhausted(self):
         return sum(self._each(lambda i, env: env.spawn_exhausted()))
 
+    def set_spawn_rates(self, agent_despawn_rate, agent_respawn_rate, grace_period, spawn_seed=None):
+        """`CookingVecEnv.set_spawn_rates` on every shard (the draws stay keyed by the global env id: the batch behaves like one handle)"""
+        self._each(lambda i, env: env.set_spawn_rates(agent_despawn_rate, agent_respawn_rate, grace_period, spawn_seed))
+
     # ------------------------------------------------------------------ device-resident API
     def alloc(self, per_env_shape, dtype, leading=()):
         """a buffer with `leading + (envs of the shard,) + per_env_shape` elements on every local shard's device"""

@@ -169,3 +169,25 @@ def test_gpus_1_equals_the_plain_run():
     assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
     da, db = (json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0]) for p in (a, b))
     assert da == db and da["value"] == pytest.approx(db["value"]) and da["device_ids"] == [0] and "config4" not in da
+
+
+def test_the_drivers_torchrun_command_dry_run():
+    """The driver's own launch form for N > 1 - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` - with `--dry-run`: torchrun's ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT from its
+    agent) find each other through the rendezvous directory derived from what they share, rank 0 prints the one line, exit code 0."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ, PYTHONPATH=REPO)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "CZ_RDZV_DIR", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"],
+                       capture_output=True, text=True, env=e, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["device_ids"] == [0, 1] and d["env_id_bases"] == [0, 4096] and d["steps"] == 20 and d["warmup"] == 5
+    assert "config4" in d and d["config4"]["envs"] == 2 * 32768

@@ -96,6 +96,12 @@ def test_shards_on_one_device_equal_one_handle(case, devices):
     if "agent_despawn_rate" in kw:
         assert ((one.get_state()[:, soa.W_STATUS] >> 8) & 0xF).any(), "somebody should be despawned at this point"
         assert one.spawn_exhausted() == many.spawn_exhausted()
+        # new rates on the live batch, across the 31-step boundary of the countdown fields (records are re-packed on every shard)
+        for env in (one, many):
+            env.set_spawn_rates(0.2, 0.4, 40)
+        one.rollout(30, 11, 500); many.rollout(30, 11, 500)
+        one.sync(); many.sync()
+        assert np.array_equal(one.get_state(), many.get_state())
     one.close(); many.close()
 
 
