@@ -11,7 +11,7 @@ record diffs; the last test of the module prints the table and asserts that noth
 the common ones in the default handful).
 
 Default: a handful of cases (seconds).  CZ_FUZZ_CASES=N widens it for one-off soak runs (200 cases are about
-37 M env-steps)."""
+37 M env-steps); CZ_FUZZ_FIRST=K starts at case K (cases are a function of their index: earlier soaks covered 0 ... 1499)."""
 import os
 
 import numpy as np
@@ -29,6 +29,7 @@ LEVELS = [("coop_test", "example", 2), ("coexistence_test", "example", 2), ("swi
 BOOK = ["TomatoSalad", "TomatoLettuceSalad", "CarrotBanana", "MashedCarrotBanana", "CucumberOnion", "AppleWatermelon",
         "TomatoLettuceOnionSalad", "no_recipe"]
 N_CASES = int(os.environ.get("CZ_FUZZ_CASES", "6"))
+FIRST_CASE = int(os.environ.get("CZ_FUZZ_FIRST", "0"))          # soak runs on cases no earlier run has drawn: CZ_FUZZ_FIRST=2000
 
 
 def draw_case(i):
@@ -74,7 +75,7 @@ def fresh_layouts(env, count, rng):
     return [[ll.instantiate(lv, env.meta, env.num_agents, r) for _ in range(count)] for lv in env.level_objects]
 
 
-@pytest.mark.parametrize("i", range(N_CASES))
+@pytest.mark.parametrize("i", range(FIRST_CASE, FIRST_CASE + N_CASES))
 def test_random_configuration_matches_oracle(i):
     kw, seed, extra = draw_case(i)
     if extra["wide"]:
@@ -208,7 +209,7 @@ def event_table():
 CORE_EVENTS = ["pick_up", "put_down", "chop", "plate_add", "static_accepts", "delivery", "marks_changed", "truncation"]
 
 
-@pytest.mark.parametrize("i", range(N_CASES))
+@pytest.mark.parametrize("i", range(FIRST_CASE, FIRST_CASE + N_CASES))
 def test_biased_actions_match_oracle(i):
     kw, seed, extra = draw_case(i)
     if extra["wide"]:
