@@ -311,6 +311,42 @@ def test_config4_one_ranks_shard():
     env.close()
 
 
+def test_config4_full_shape_eight_shards_on_one_device():
+    """BASELINE config 4 in its full shape - 262 144 envs cut into 8 shards of 32 768, global env ids - on the one device a box has:
+    `ShardedVecEnv(device_ids=[0] * 8)` = eight handles, eight streams, eight host threads, the statistics of eight shards; only RCCL's
+    transport between DISTINCT devices is replaced by the host reduction (RCCL refuses duplicate devices).  Against the oracle over the
+    whole batch: host-array steps with every output compared, then a fused rollout over the on-device action stream (keyed by the global
+    id, so the shards draw what one handle over 262 144 envs would draw)."""
+    from cooking_zoo_amd import ShardedVecEnv
+    from oracle_binding import ShardedOracle
+    n, A, G = 262144, 2, 8
+    senv = ShardedVecEnv(n, "coop_test", "example", A, 14, ["TomatoLettuceSalad", "CarrotBanana"], action_scheme="scheme3", num_layouts=256,
+                         auto_reset=True, device_ids=[0] * G, comm="host")
+    assert senv.ranges == [(g * 32768, 32768) for g in range(G)] and senv.comm_kind == "host"
+    orc = ShardedOracle(senv.tables)
+    senv.reset(return_obs=False)
+    orc.reset()
+    rng = np.random.default_rng(43)
+    for t in range(5):
+        acts = rng.integers(0, 5, size=(n, A), dtype=np.int32)
+        og, rg, tg, ug = senv.step(acts)
+        oo, ro, to, uo = orc.step(acts)
+        assert np.array_equal(bits(rg), bits(ro)) and np.array_equal(tg, to) and np.array_equal(ug, uo), f"rewards / flags @ step {t}"
+        assert np.array_equal(bits(og), bits(oo)), f"obs @ step {t}"
+        del og, oo
+    T = 32
+    senv.rollout(T, 44, 700)
+    senv.sync()
+    orc.rollout(T, 44, 700, want_obs=False)
+    assert np.array_equal(strip(senv.get_state()), orc.records), "records after the fused rollout"
+    per = senv.stats_per_shard()
+    assert len(per) == G and all(p["env_steps"] > 32768 * (5 + T) * 0.9 for p in per)
+    st = senv.stats()
+    assert st["env_steps"] == sum(p["env_steps"] for p in per)
+    assert st["episodes"] == int(orc.records[:, soa.W_EPISODE].sum()) + int((orc.records[:, soa.W_STATUS] & 1).sum())
+    senv.close()
+
+
 def test_stats_reduction_order_and_size():
     """The two-stage statistics reduction (64 workgroups of chains + one tree) against a numpy model of its fixed
     summation order, bit for bit, at 65 536 envs: chain c adds envs c, c+256, ... in order, then a binary tree."""
