@@ -546,6 +546,44 @@ def leg_configs(device_id, which=("config3", "config5", "config4_shard")):
     return out
 
 
+def leg_config4_on_one_gpu(device_id):
+    """BASELINE config 4's WHOLE batch - 262 144 envs as eight shards of 32 768 with global env ids - on this one GPU (288 GB hold it):
+    ShardedVecEnv(device_ids=[d] * 8), i.e. eight handles / streams / host threads, statistics reduced on the host (RCCL refuses
+    duplicate devices).  Per env step: eight launches of the one-step kernel, one per shard.  What eight GPUs do in parallel this does
+    in turn - the number is a lower bound of the 8-GPU value / 8, and evidence that the configuration runs in its full shape
+    (parity of the same shape: tests/test_gpu_large.py::test_config4_full_shape_eight_shards_on_one_device)."""
+    from cooking_zoo_amd.sharded import ShardedVecEnv
+    G, K, R = 8, 50, 5
+    n = CFG4_ENVS_PER_GPU * G
+    senv = ShardedVecEnv(n, *WORKLOAD, device_ids=[device_id] * G, comm="host", **WORKLOAD_KW)
+    try:
+        senv.reset(return_obs=False)
+        period = 16
+        ring = senv.alloc((2,), np.int32, leading=(period,))
+        ring.from_host(np.random.default_rng(7).integers(0, 5, size=(period, n, 2), dtype=np.int32))
+        outs = (senv.alloc((2, senv.F), np.float64), senv.alloc((2,), np.float64), senv.alloc((2,), np.uint8), senv.alloc((2,), np.uint8))
+        senv.ring_prepare(K, ring, period, 0, *outs)
+        senv.step_device_ring(K, ring, period, 0, *outs)
+        senv.sync()
+        ts = []
+        for _ in range(R):
+            senv.sync()
+            t0 = time.perf_counter()
+            senv.step_device_ring(K, ring, period, 0, *outs)
+            senv.sync()
+            ts.append((time.perf_counter() - t0) * 1e6 / K)
+        us = float(np.median(ts))
+        b_alg = algorithmic_bytes_per_env_step(senv.shards[0])
+        st = senv.stats()
+        return {"workload": f"{n} envs = {G} shards of {CFG4_ENVS_PER_GPU} (global env ids) on ONE device, coop_test, 2 agents; {K}-step ring runs, median of {R}",
+                "envs": n, "shards": [list(r) for r in senv.ranges], "us_per_step_of_the_whole_batch": us,
+                "env_steps_per_s": 400.0 / 401.0 * n / (us * 1e-6), "stats_env_steps": st["env_steps"],
+                "roofline": roofline_block(b_alg, n, us, "cz::k_step<1,1,2,3,0> x 8 shards per env step",
+                                           "wall clock of the ring runs of all eight shards (eight streams of one device)")}
+    finally:
+        senv.close()
+
+
 def guarded(fn, *a, **kw):
     """an extra leg of the line: its result, or {"error": ...} - never an exception that would lose the headline"""
     try:
@@ -890,6 +928,8 @@ def worker_body(args, rdzv):
             line["closed_loop_caller_graph"] = guarded(leg_closed_loop_captured, env, d_obs, d_rew, d_term, d_trunc)
             line["cooking_policy"] = guarded(leg_cooking_policy, local_rank)
             line["configs"] = guarded(leg_configs, local_rank)
+            if isinstance(line["configs"], dict) and "error" not in line["configs"]:
+                line["configs"]["config4_on_one_gpu"] = guarded(leg_config4_on_one_gpu, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = guarded(cpu_baseline, env)
         emit(line)

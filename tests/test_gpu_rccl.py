@@ -82,6 +82,8 @@ def test_bench_driver_command_exits_zero_with_every_leg():
     for leg in ("fused_rollout", "fused_actions", "fused_compact", "ring_fused", "closed_loop", "closed_loop_compact",
                 "closed_loop_caller_graph", "cooking_policy", "configs"):
         assert leg in d and "error" not in d[leg], (leg, d.get(leg))
+    c4 = d["configs"]["config4_on_one_gpu"]                       # config 4's whole batch as eight shards on this one device
+    assert "error" not in c4 and c4["envs"] == 262144 and c4["shards"][3] == [98304, 32768] and c4["env_steps_per_s"] > 1e8, c4
 
 
 def test_two_ranks_on_one_device_agree_on_the_outcome():
