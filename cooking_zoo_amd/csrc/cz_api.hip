@@ -898,10 +898,13 @@ static int launch_step(cz_handle h, Params &P, hipStream_t stream = nullptr, boo
                        "again (it maps every layout to the level whose spawn areas it uses)", h->n_layouts);
     if (!stream) stream = h->stream;
     // write-through observation stores pay when the launch is short enough for the end-of-kernel L2 write-back to be
-    // exposed: one step of a moderate batch; streaming stores when one launch's observations do not fit the memory-side
-    // cache (256 MiB) any more.  (CZ_WT=0/1/2 overrides, for experiments.)
+    // exposed: one step of a batch of up to ~10 000 envs, whatever its rows weigh (round 6, profiles/r06/wt_sizes.txt: the 2.2 KB
+    // rows of the 7x7 levels cross over between 10 240 and 12 288 envs - 43 / 52 MiB -, the 6.7 KB rows of large_16x16 are still
+    // ahead at 8192 envs = 210 MiB; until round 5 the rule was "up to 128 MiB", which cost the 7x7 levels 5-9 % from 12 288 to
+    // 24 576 envs and large_16x16 2-7 % from 6144 to 8192); streaming stores when one launch's observations do not fit the
+    // memory-side cache (256 MiB) any more.  (CZ_WT=0/1/2 overrides, for experiments.)
     const size_t obs_bytes = (size_t)P.N * P.A * P.F * 8;
-    if (!fused) P.wt = obs_bytes <= ((size_t)128 << 20) ? 1 : obs_bytes > ((size_t)224 << 20) ? 2 : 0;
+    if (!fused) P.wt = obs_bytes > ((size_t)224 << 20) ? 2 : P.N <= 10240 ? 1 : 0;
     // (fused: streaming stores only when an agent's row fills whole DRAM pages - 4 KiB and more, config 5: +8 %; with the
     // 2.2 KB rows of the 7x7 levels they lose 15 % against the cache's own write-back order, profiles/r03/wt_ab2.txt)
     else P.wt = (obs_bytes > ((size_t)224 << 20) && (size_t)P.F * 8 >= 4096) ? 2 : 0;
