@@ -4,7 +4,7 @@
 R=${1:?round directory name}
 O=gpurun_out/$R; mkdir -p $O
 : > $O/size_sweep.txt
-for n in 512 1024 2048 4096 8192 16384 32768 65536 131072; do
+for n in 512 1024 2048 4096 6144 8192 12288 16384 24576 32768 65536 131072; do
   timeout 300 python3 bench.py --envs $n --steps 400 --warmup 40 --repeats 10 --no-extras --no-cpu-baseline 2> /dev/null | python3 -c "
 import json, sys
 d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
